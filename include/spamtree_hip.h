@@ -1,0 +1,139 @@
+/* spamtree_hip.h -- C-ABI of the MI355X (gfx950) build of spamtree's per-Gibbs-sweep DAG-node hot path.
+ *
+ * The boundary sits UNDER the reference's `SpamTreeMV` model object (/root/reference/src/spamtree_model.h:22-212):
+ * each entry point replaces one of its hot methods; the host driver above it (spamtree_mv_mcmc,
+ * /root/reference/src/spamtree_fit.cpp:5-430) keeps owning the RNG, the Metropolis step and the outputs.
+ * Plain pointers and sizes only; no C++ / torch types.  All matrices are column-major doubles (Armadillo's
+ * layout), all index vectors int64 and 0-based unless stated, rows are in the order R hands them to C++
+ * (sorted by coordinates, /root/reference/R/spamtree_fit.R:267-269).  Pointers are borrowed for the call only;
+ * the handle owns every device allocation.  One host thread per handle; the handle is not re-entrant.
+ *
+ * Return value of every function: 0 = ok; 1/2/3 = Cholesky failed in phase A at the root / a reference block /
+ * a non-reference row (the reference's `errtype`, spamtree_model.cpp:876, 919, 958); 10/11 = Cholesky failed in
+ * the w sweep (spamtree_model.cpp:1056, 1135); negative = usage / HIP error (st_last_error() has the text).
+ * No exception crosses this boundary.
+ */
+#ifndef SPAMTREE_HIP_H
+#define SPAMTREE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ST_OK 0
+#define ST_ERR_CHOL_ROOT 1
+#define ST_ERR_CHOL_REF 2
+#define ST_ERR_CHOL_LEAF 3
+#define ST_ERR_CHOL_SAMPLE_REF 10
+#define ST_ERR_CHOL_SAMPLE_LEAF 11
+#define ST_ERR_USAGE (-1)
+#define ST_ERR_HIP (-2)
+#define ST_ERR_TOPOLOGY (-3)
+#define ST_ERR_UNSUPPORTED (-4)
+
+#define ST_MAX_Q 6          /* outcomes (theta has 3q + (q>2?3:1) + q(q-1)/2 <= 39 entries) */
+#define ST_MAX_ANCESTORS 24 /* tree depth - 1 */
+
+typedef struct st_handle_s *st_handle;
+
+/* Inputs of the SpamTreeMV constructor (spamtree_model.cpp:8-37) that the hot path needs. */
+typedef struct st_problem {
+  int64_t n_all;               /* rows (observed + NA)                                   coords.n_rows            */
+  int32_t d;                   /* coordinate columns, must be 2                           coords.n_cols            */
+  int32_t q;                   /* outcomes                                                unique(mv_id)            */
+  int32_t p;                   /* regressors                                              X.n_cols                 */
+  int32_t n_groups;            /* length of res_is_ref                                                             */
+  int64_t n_blocks;            /*                                                         block_names.n_elem       */
+  const double *y;             /* n_all, NaN = NA                                         y_in                     */
+  const double *X;             /* n_all x p column-major                                  X_in                     */
+  const double *coords;        /* n_all x d column-major                                  coords_in                */
+  const int64_t *mv_id;        /* n_all, 1-based outcome id                               mv_id_in                 */
+  const int64_t *res_is_ref;   /* n_groups flags, indexed by level rank                   res_is_ref_in            */
+  const int64_t *block_names;  /* n_blocks, 1-based ids                                   block_names_in           */
+  const int64_t *block_groups; /* n_blocks, level ("res") of block id-1                   block_groups_in          */
+  const int64_t *indexing_ptr; /* n_blocks+1 CSR offsets                                  indexing_in (field)      */
+  const int64_t *indexing_idx; /* row ids of each block, ascending                                                 */
+  const int64_t *parents_ptr;  /* n_blocks+1                                              parents_in (field)       */
+  const int64_t *parents_idx;  /* ancestor block ids, ascending (root first)                                       */
+  const int64_t *children_ptr; /* n_blocks+1, may be NULL (derived from parents)          children_in (field)      */
+  const int64_t *children_idx; /* all non-empty descendants, ascending; may be NULL                                */
+} st_problem;
+
+typedef struct st_options {
+  int32_t device;              /* HIP device ordinal                                                               */
+  int32_t reference_quirks;    /* 1 = reproduce spamtree_model.cpp:1375 (Q3: beta uses subset positions on full w) */
+  int32_t rank;                /* multi-GPU: this process' rank ...                                                */
+  int32_t world;               /* ... of `world` processes sharing one problem (1 = single GPU)                    */
+  int32_t force_generic;       /* 1 = use the global-scratch kernels even where the LDS kernels fit (testing)      */
+  int32_t reserved;
+} st_options;
+
+/* ---- lifetime: SpamTreeMV::SpamTreeMV (spamtree_model.cpp:8-192) incl. init_indexing/init_finalize/init_model_data */
+int st_create(const st_problem *pb, const st_options *opt, st_handle *out);
+int st_destroy(st_handle h);
+const char *st_last_error(st_handle h); /* h may be NULL: error text of the last failed st_create */
+
+/* ---- state the driver reads / writes directly in the reference (public fields w, Bcoeff, tausq_inv) */
+int st_set_w(st_handle h, const double *w);                /* n_all, model row order */
+int st_get_w(st_handle h, double *w);
+int st_set_beta(st_handle h, const double *Bcoeff);        /* p x q column-major; recomputes XB (spamtree_model.cpp:127, 1382) */
+int st_set_tausq_inv(st_handle h, const double *tausq_inv);/* q (spamtree_model.cpp:118, 1405-1407) */
+int st_get_xb(st_handle h, double *xb);                    /* n_all */
+
+/* ---- phase A: theta_update + get_loglik_comps_w(data) (spamtree_model.cpp:834-998, 1420-1422).
+ * slot 0 = param_data, 1 = alter_data.  Returns 0 (the reference's `true`) or 1/2/3 (`false`, errtype);
+ * *loglik = data.loglik_w (undefined on failure).  theta has ntheta = 3q + (q>2?3:1) + q(q-1)/2 entries. */
+int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik);
+
+/* ---- accept_make_change (spamtree_model.cpp:1432-1435): swap the two cache slots */
+int st_swap(st_handle h);
+
+/* ---- phase B: gibbs_sample_w_std(true) on param_data (spamtree_model.cpp:1011-1226).
+ * z = the reference's bigrnorm (n_all standard normals, model row order).  z == NULL: generate on device,
+ * z_i = normal(Philox4x32-10; key=seed, counter=(row, row>>32, iter, 0)) -- identical for any GPU count. */
+int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter);
+
+/* ---- phase C: get_loglik_w_std(data) (spamtree_model.cpp:781-826) */
+int st_loglik_w(st_handle h, int slot, double *loglik);
+
+/* ---- phase P: predict_std(true, theta_changed) on param_data (spamtree_model.cpp:1234-1358); uses the last sweep's z */
+int st_predict(st_handle h, int theta_changed);
+
+/* ---- reductions for gibbs_sample_beta / gibbs_sample_tausq (spamtree_model.cpp:1374-1375, 1397-1400).
+ * xty: p x q column-major, column j = X_avail_j' (y_avail_j - w[...]);  ssq: q, sum (y - XB - w)^2 over observed rows.
+ * n_obs_by_q: q (may be NULL).  The draws themselves (R::rgamma, arma::randn) stay with the host driver. */
+int st_beta_stats(st_handle h, double *xty);
+int st_tausq_stats(st_handle h, double *ssq, int64_t *n_obs_by_q);
+int st_xtx(st_handle h, double *xtx);                      /* p x p x q, XtX(j) of spamtree_model.cpp:151-155 */
+
+/* ---- yhat = XB + w + tausq^{1/2} * normal (spamtree_fit.cpp:384); noise==NULL: device stream 5 */
+int st_yhat(st_handle h, const double *noise, uint64_t seed, uint32_t iter, double *yhat);
+
+/* ---- inspection (parity tests): per-block caches of a slot.
+ * For block u (0-based id) with m rows and P ancestor rows the build keeps the inverse-Cholesky row panel
+ * [ -Ri*H | Ri ] (tree_utils.cpp:204-206) instead of H, Kxx_inv, Kxx_invchol separately.
+ * st_block_dims: *m, *P, *is_ref.  st_get_block: negRiH (m x P, column-major) and Ri (m x m column-major for a
+ * reference block, m diagonal entries for a non-reference block). */
+int st_block_dims(st_handle h, int64_t u, int64_t *m, int64_t *P, int32_t *is_ref, int32_t *n_obs);
+int st_get_block(st_handle h, int slot, int64_t u, double *negRiH, double *Ri);
+int st_get_comps(st_handle h, int slot, double *logdetCi_comps, double *loglik_w_comps); /* n_blocks each */
+
+/* ---- measurement: algorithmic bytes of one iteration (SURVEY.md section 8d operand-streaming model)
+ * out[0..4] = phase A, B, C, messages, S1+S2;  flops[0..2] = A, B, C (may be NULL). */
+int st_algorithmic_bytes(st_handle h, double *out5, double *flops3);
+/* per-kernel-family device time, HIP events on the launch stream.  enable=1 brackets every launch with events
+ * (serialises; use outside the timed region).  names: 0 factor(A) 1 sample(B) 2 loglik(C) 3 reduce 4 stats 5 rng 6 predict */
+#define ST_N_KERNEL_FAMILIES 7
+int st_profile_enable(st_handle h, int enable);
+int st_profile_get(st_handle h, double *ms_total, int64_t *launches); /* ST_N_KERNEL_FAMILIES each; resets */
+/* per-level phase-A launch statistics of the last profiled st_factor: ms and algorithmic bytes per level */
+int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, double *bytes_by_level, int32_t cap);
+int st_synchronize(st_handle h);
+void *st_stream(st_handle h);                              /* the hipStream_t every kernel is launched on */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPAMTREE_HIP_H */

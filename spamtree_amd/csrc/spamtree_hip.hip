@@ -1,0 +1,1499 @@
+// spamtree_hip.hip -- gfx950 kernels + C-ABI for spamtree's per-Gibbs-sweep DAG-node linear algebra.
+//
+// What each kernel replaces in the reference (paths relative to /root/reference/src):
+//   k_factor<MODE_FACTOR>  spamtree_model.cpp:834-998  get_loglik_comps_w_std  (phase A)  + covariance_functions.cpp:95-111, 213-286
+//   k_factor<MODE_PREDICT> spamtree_model.cpp:1234-1358 predict_std            (phase P)
+//   k_sample               spamtree_model.cpp:1011-1226 gibbs_sample_w_std     (phase B)
+//   k_loglik               spamtree_model.cpp:781-826  get_loglik_w_std        (phase C)
+//   k_stats / k_xb         spamtree_model.cpp:1374-1375, 1382, 1397-1400       (beta / tausq sufficient statistics)
+//
+// Design (DESIGN.md has the derivation): the reference materialises, per block u with ancestor rows PI_u,
+// H_u = K_{u,pa} K_{pa,pa}^{-1}, the dense (P+m)^2 inverse Cholesky of K_{[pa,u]} and its Gram matrix.  The inverse
+// Cholesky of an ancestor set is block lower triangular and its row panel for block a is [-Ri_a H_a | Ri_a]
+// (tree_utils.cpp:204-206), so this build stores exactly ONE array per block, that panel ("Linv panel",
+// m x (P+m), row-major), and every phase works from the chain of ancestor panels:
+//   V = Linv_pa * K_{pa,u}            (one pass over the chain, ancestors last-to-first so V overwrites K in place)
+//   T = V' * Linv_pa = H_u            (accumulated in the same pass)
+//   R = K_uu - V'V,  Ri = chol(R)^{-1},  panel_u = [-Ri*T | Ri]
+// Messages to ancestors are pushed as per-ancestor (m_a x m_a, m_a) pairs and summed hierarchically through
+// direct children in a fixed order (no FP64 atomics -> bit-reproducible for any launch geometry).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "spamtree_hip.h"
+
+#define NT 256
+#define MAXJ ST_MAX_ANCESTORS
+#define QMAX ST_MAX_Q
+#define HL2PI (-0.91893853320467274178032973640562)
+
+struct CovPar {
+  int q;
+  int ncb;
+  double ai1[QMAX], ai2[QMAX], phi[QMAX];
+  double tmv[3];
+  double D[QMAX * QMAX];
+};
+
+struct Blk {
+  long long row0;       // first device row
+  long long panel_off;  // doubles, into a slot's panel arena (-1: none)
+  long long acc_off;    // doubles, into the message arena
+  int m, P, nanc, anc_ptr;
+  int isref, nobs, dch_ptr, ndch;
+  int acc_len, level, ld, model_id;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cov_entry(const CovPar &c, double xi, double yi, int vi, double xj, double yj, int vj) {
+  const double dx = xi - xj, dy = yi - yj;
+  const double h = sqrt(dx * dx + dy * dy);
+  if (c.q == 1) return c.ai1[0] * exp(-c.tmv[0] * h);  // cexpcov: sigmasq = ai1(0), phi = thetamv(0)
+  const double v = c.D[vi * c.q + vj];
+  double cb;  // C_base(h, 0, v)
+  if (c.q > 2) {
+    const double ps = exp(0.5 * c.tmv[1] * log1p(c.tmv[0] * v));
+    cb = exp(-c.tmv[2] * (h / ps)) / (ps * ps);
+  } else {
+    const double ps = sqrt(v + 1.0);
+    cb = exp(-c.tmv[0] * (h / ps)) / (v + 1.0);
+  }
+  if (v == 0.0) return c.ai1[vi] * c.ai1[vi] * cb + c.ai2[vi] * c.ai2[vi] * exp(-c.phi[vi] * h);
+  return c.ai1[vi] * c.ai1[vj] * cb;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of one double per thread; result valid in every thread. red: >= NT/64 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wv] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+// In-place lower Cholesky of the m x m row-major matrix A (lower triangle referenced).  *fail set when a pivot
+// is not > 0 (LAPACK dpotrf's test, NaN included).  All threads of the block must call.
+__device__ void chol_lower_inplace(double *A, int m, int *fail) {
+  for (int k = 0; k < m; ++k) {
+    __syncthreads();
+    const double d = A[k * m + k];
+    if (!(d > 0.0)) {
+      if (threadIdx.x == 0) *fail = 1;
+    }
+    const double piv = sqrt(d);
+    __syncthreads();
+    for (int i = k + threadIdx.x; i < m; i += blockDim.x) A[i * m + k] = (i == k) ? piv : A[i * m + k] / piv;
+    __syncthreads();
+    const int r = m - k - 1;
+    for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
+      const int i = k + 1 + idx / r, j = k + 1 + idx % r;
+      if (j <= i) A[i * m + j] -= A[i * m + k] * A[j * m + k];
+    }
+  }
+  __syncthreads();
+}
+
+// Ri = L^{-1} (lower, zeros above the diagonal), one thread per column.
+__device__ void tri_inverse_lower(const double *L, double *Ri, int m) {
+  for (int j = threadIdx.x; j < m; j += blockDim.x) {
+    for (int i = 0; i < j; ++i) Ri[i * m + j] = 0.0;
+    for (int i = j; i < m; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int k = j; k < i; ++k) s -= L[i * m + k] * Ri[k * m + j];
+      Ri[i * m + j] = s / L[i * m + i];
+    }
+  }
+  __syncthreads();
+}
+
+// Philox4x32-10 (Salmon et al. 2011) -- same stream contract as oracle.StRng
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(unsigned a, unsigned b) {
+  return ((double)(((unsigned long long)(a >> 5) << 26) + (unsigned long long)(b >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double philox_normal(unsigned long long idx, unsigned iter, unsigned stream, unsigned long long seed) {
+  unsigned o[4];
+  philox4x32_10((unsigned)idx, (unsigned)(idx >> 32), iter, stream, (unsigned)seed, (unsigned)(seed >> 32), o);
+  const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
+  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+__global__ void k_normals(double *z, const long long *dev2model, long long n, unsigned iter, unsigned stream, unsigned long long seed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) z[i] = philox_normal((unsigned long long)dev2model[i], iter, stream, seed);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase A / P : per block, one workgroup.  BIG=false keeps K/V, T, the row stage and the m x m factors in LDS;
+// BIG=true keeps them in a per-workgroup slice of a global scratch arena (any m, P).
+// ---------------------------------------------------------------------------------------------------------------
+struct FactorArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const int *list;  // device block ids to process
+  int nlist;
+  const double *cx, *cy;
+  const int *mv;
+  const double *w_in;   // current w (device order)
+  double *w_out;        // predict: where samples go
+  const double *z;      // predict: normals (device order)
+  double *panels;       // slot arena
+  double *logdet_c, *loglik_c;
+  int *errflag;         // atomicMin(level*16 + code)
+  double *scratch;      // BIG
+  long long scratch_stride;
+  int maxP, maxM, maxMa, SR;
+};
+
+#define MODE_FACTOR 0
+#define MODE_PREDICT 1
+
+template <bool BIG, int MODE>
+__global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
+  extern __shared__ double lds[];
+  __shared__ int s_anc[MAXJ], s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
+  __shared__ int s_fail;
+  __shared__ double s_red[NT / 64];
+
+  const int tid = threadIdx.x;
+  const int maxP = A.maxP, maxM = A.maxM, maxMa = A.maxMa, SR = A.SR;
+  // LDS carve
+  double *sx = lds;
+  double *sy = sx + (maxP + maxM);
+  double *wv = sy + (maxP + maxM);
+  double *hv = wv + (maxP + maxM);     // maxM
+  double *ev = hv + maxM;              // maxM
+  double *rd = ev + maxM;              // maxM
+  double *stage = rd + maxM;           // SR * maxP
+  int *smv = (int *)(stage + (size_t)SR * maxP);
+  double *big0 = (double *)(smv + ((maxP + maxM + 1) & ~1));
+  double *KV, *Tt, *Vp, *R, *Ri;
+  if (BIG) {
+    double *g = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    KV = g; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
+  } else {
+    KV = big0; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
+  }
+
+  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
+    const int b = A.list[li];
+    const Blk B = A.blks[b];
+    const int m = B.m, P = B.P, J = B.nanc;
+    __syncthreads();
+    if (tid < J) {
+      const int a = A.anc_idx[B.anc_ptr + tid];
+      s_anc[tid] = a;
+      s_am[tid] = A.blks[a].m;
+      s_arow[tid] = A.blks[a].row0;
+      s_apan[tid] = A.blks[a].panel_off;
+    }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+      s_ao[J] = o;
+    }
+    __syncthreads();
+    for (int t = 0; t < J; ++t) {
+      const long long r0 = s_arow[t];
+      const int oa = s_ao[t];
+      for (int i = tid; i < s_am[t]; i += NT) {
+        sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i];
+      }
+    }
+    for (int i = tid; i < m; i += NT) {
+      sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
+    }
+    __syncthreads();
+    // K_{pa,u}  (covariance_functions.cpp:95-111 / :213-286), T = 0
+    for (int idx = tid; idx < P * m; idx += NT) {
+      const int k = idx / m, j = idx - k * m;
+      KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
+      Tt[idx] = 0.0;
+    }
+    __syncthreads();
+    // one pass over the ancestor chain, last ancestor first
+    for (int t = J - 1; t >= 0; --t) {
+      const int ma = s_am[t], oa = s_ao[t], Kb = oa + ma;
+      const double *pa = A.panels + s_apan[t];
+      for (int r0 = 0; r0 < ma; r0 += SR) {
+        const int sr = min(SR, ma - r0);
+        const double *src = pa + (size_t)r0 * Kb;
+        for (int idx = tid; idx < sr * Kb; idx += NT) stage[idx] = src[idx];
+        __syncthreads();
+        for (int idx = tid; idx < sr * m; idx += NT) {
+          const int i = idx / m, j = idx - i * m;
+          const double *srow = stage + i * Kb;
+          double acc = 0.0;
+          for (int k = 0; k < Kb; ++k) acc += srow[k] * KV[k * m + j];
+          Vp[(r0 + i) * m + j] = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * Kb; idx += NT) {
+          const int j = idx / Kb, k = idx - j * Kb;
+          double acc = Tt[j * P + k];
+          for (int i = 0; i < sr; ++i) acc += Vp[(r0 + i) * m + j] * stage[i * Kb + k];
+          Tt[j * P + k] = acc;
+        }
+        __syncthreads();
+      }
+      for (int idx = tid; idx < ma * m; idx += NT) KV[oa * m + idx] = Vp[idx];
+      __syncthreads();
+    }
+    // hv = H w_pa  (wave per row)
+    {
+      const int lane = tid & 63, wid = tid >> 6;
+      for (int j = wid; j < m; j += NT / 64) {
+        double acc = 0.0;
+        for (int k = lane; k < P; k += 64) acc += Tt[j * P + k] * wv[k];
+        acc = wave_sum(acc);
+        if (lane == 0) hv[j] = acc;
+      }
+    }
+    __syncthreads();
+
+    if (MODE == MODE_PREDICT) {
+      // spamtree_model.cpp:1306-1326: w_i = H_i w_pa + sqrt(max(K_ii - H_i K_{pa,i}, 0)) z_i
+      for (int i = tid; i < m; i += NT) {
+        double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
+        for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + i];
+        const double sd = (acc > 0.0) ? sqrt(acc) : 0.0;
+        A.w_out[B.row0 + i] = hv[i] + sd * A.z[B.row0 + i];
+      }
+      continue;
+    }
+
+    double *pu = A.panels + B.panel_off;
+    const int ld = B.ld;
+    double wcore_part = 0.0, logdet_part = 0.0;
+    if (B.isref) {
+      // R = K_uu - V'V  (lower), chol, inverse
+      for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        if (j <= i) {
+          double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]);
+          for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + j];
+          R[idx] = acc;
+        } else {
+          R[idx] = 0.0;
+        }
+      }
+      chol_lower_inplace(R, m, &s_fail);
+      tri_inverse_lower(R, Ri, m);
+      // panel_u = [ -Ri*T | Ri ]
+      for (int idx = tid; idx < m * P; idx += NT) {
+        const int i = idx / P, k = idx - i * P;
+        double acc = 0.0;
+        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * Tt[j * P + k];
+        pu[(size_t)i * ld + k] = -acc;
+      }
+      for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        pu[(size_t)i * ld + P + j] = Ri[idx];
+      }
+      // e = Ri (w_u - H w_pa)
+      for (int i = tid; i < m; i += NT) {
+        double acc = 0.0;
+        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * (wv[P + j] - hv[j]);
+        wcore_part += acc * acc;
+        logdet_part += log(Ri[i * m + i]);
+      }
+    } else {
+      // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963)
+      for (int i = tid; i < m; i += NT) {
+        double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
+        for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + i];
+        if (!(acc > 0.0)) s_fail = 1;
+        const double r = 1.0 / sqrt(acc);
+        rd[i] = r;
+        pu[(size_t)i * ld + P] = r;
+        const double e = r * (wv[P + i] - hv[i]);
+        wcore_part += e * e;
+        logdet_part += log(r);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < m * P; idx += NT) {
+        const int i = idx / P, k = idx - i * P;
+        pu[(size_t)i * ld + k] = -rd[i] * Tt[idx];
+      }
+    }
+    const double wcore = block_sum(wcore_part, s_red);
+    const double logdet = block_sum(logdet_part, s_red);
+    __syncthreads();
+    if (tid == 0) {
+      A.logdet_c[b] = logdet;
+      A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
+      if (s_fail) atomicMin(A.errflag, B.level * 16 + (J == 0 ? 1 : (B.isref ? 2 : 3)));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B: block-Gibbs draw of w_u + message push (spamtree_model.cpp:1011-1226), one workgroup per block.
+// ---------------------------------------------------------------------------------------------------------------
+struct SampleArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const int *dch_idx;
+  const int *list;
+  int nlist;
+  const double *panels;  // param_data slot
+  double *w;
+  const double *y, *xb, *z;
+  const int *mv;
+  const unsigned char *obs;
+  double *acc;           // message arena
+  int *errflag;
+  double *scratch;       // BIG: staged S matrix
+  long long scratch_stride;
+  int maxP, maxM, maxLd;
+  double tausq_inv[QMAX];
+};
+
+template <bool BIG>
+__global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ];
+  __shared__ int s_fail;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int maxP = A.maxP, maxM = A.maxM;
+  double *wv = lds;                    // maxP + maxM
+  double *tv = wv + (maxP + maxM);     // maxM   N w_pa
+  double *ev = tv + maxM;              // maxM   Ri w_u + N w_pa
+  double *bv = ev + maxM;              // maxM   rhs / solution
+  double *av = bv + maxM;              // maxM   per-ancestor temp
+  double *Np = av + maxM;              // !BIG: maxM * maxLd panel copy
+  double *S = BIG ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
+
+  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
+    const int b = A.list[li];
+    const Blk B = A.blks[b];
+    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+    __syncthreads();
+    if (tid < J) {
+      const int a = A.anc_idx[B.anc_ptr + tid];
+      s_am[tid] = A.blks[a].m;
+      s_arow[tid] = A.blks[a].row0;
+    }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+      s_ao[J] = o;
+    }
+    __syncthreads();
+    for (int t = 0; t < J; ++t) {
+      const long long r0 = s_arow[t];
+      for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[r0 + i];
+    }
+    const double *pg = A.panels + B.panel_off;
+    const double *N;  // m x ld, row-major: [ -Ri*H | Ri or r ]
+    if (BIG) {
+      N = pg;
+    } else {
+      for (int idx = tid; idx < m * ld; idx += NT) Np[idx] = pg[idx];
+      N = Np;
+    }
+    __syncthreads();
+    for (int i = wid; i < m; i += NT / 64) {
+      double acc = 0.0;
+      for (int k = lane; k < P; k += 64) acc += N[(size_t)i * ld + k] * wv[k];
+      acc = wave_sum(acc);
+      if (lane == 0) tv[i] = acc;
+    }
+    __syncthreads();
+
+    if (B.isref) {
+      const double *Ri = N + P;  // Ri[i][j] = N[i*ld + P + j]
+      // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
+      for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        if (j <= i) {
+          double acc = 0.0;
+          for (int k = i; k < m; ++k) acc += Ri[(size_t)k * ld + i] * Ri[(size_t)k * ld + j];
+          for (int c = 0; c < B.ndch; ++c) {
+            const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
+            acc += A.acc[C.acc_off + B.acc_len + idx];
+          }
+          if (i == j) acc += A.tausq_inv[A.mv[B.row0 + i]];
+          S[idx] = acc;
+        } else {
+          S[idx] = 0.0;
+        }
+      }
+      // Smu_tot = A_u' w_pa + sum_children Smu_children + tausq_inv*(y - XB)   (:1062-1077)
+      for (int i = tid; i < m; i += NT) {
+        double acc = 0.0;
+        for (int k = i; k < m; ++k) acc -= Ri[(size_t)k * ld + i] * tv[k];
+        for (int c = 0; c < B.ndch; ++c) {
+          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
+          acc += A.acc[C.acc_off + B.acc_len + m * m + i];
+        }
+        const long long r = B.row0 + i;
+        acc += A.tausq_inv[A.mv[r]] * (A.y[r] - A.xb[r]);
+        bv[i] = acc;
+      }
+      chol_lower_inplace(S, m, &s_fail);
+      // w_u = L^{-T} (L^{-1} Smu + z)   (= Sigi_chol' (Sigi_chol Smu + z), :1086)
+      for (int k = 0; k < m; ++k) {
+        __syncthreads();
+        const double xk = bv[k] / S[k * m + k];
+        __syncthreads();
+        if (tid == 0) bv[k] = xk;
+        for (int i = k + 1 + tid; i < m; i += NT) bv[i] -= S[i * m + k] * xk;
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) bv[i] += A.z[B.row0 + i];
+      for (int k = m - 1; k >= 0; --k) {
+        __syncthreads();
+        const double xk = bv[k] / S[k * m + k];
+        __syncthreads();
+        if (tid == 0) bv[k] = xk;
+        for (int i = tid; i < k; i += NT) bv[i] -= S[k * m + i] * xk;
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) {
+        wv[P + i] = bv[i];
+        A.w[B.row0 + i] = bv[i];
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) {
+        double acc = tv[i];
+        for (int j = 0; j <= i; ++j) acc += Ri[(size_t)i * ld + j] * wv[P + j];
+        ev[i] = acc;
+      }
+    } else {
+      // non-reference rows (:1091-1155)
+      for (int i = tid; i < m; i += NT) {
+        const long long r = B.row0 + i;
+        const double ri = N[(size_t)i * ld + P];
+        const double tsq = A.tausq_inv[A.mv[r]];
+        const double sig = ri * ri + tsq;
+        if (!(sig > 0.0)) s_fail = 1;
+        const double mu = -ri * tv[i] + tsq * (A.y[r] - A.xb[r]);
+        const double c = 1.0 / sqrt(sig);
+        const double wi = c * c * mu + c * A.z[r];
+        wv[P + i] = wi;
+        A.w[r] = wi;
+        ev[i] = ri * wi + tv[i];
+      }
+    }
+    __syncthreads();
+    // messages to every ancestor (:1158-1207), summed with the direct children's accumulated messages
+    long long off = 0;
+    for (int t = 0; t < J; ++t) {
+      const int ma = s_am[t], oa = s_ao[t];
+      for (int r = tid; r < m; r += NT) {
+        double acc = ev[r];
+        for (int j = 0; j < ma; ++j) acc -= N[(size_t)r * ld + oa + j] * wv[oa + j];
+        av[r] = acc;
+      }
+      __syncthreads();
+      double *out = A.acc + B.acc_off + off;
+      for (int idx = tid; idx < ma * ma + ma; idx += NT) {
+        double acc = 0.0;
+        if (idx < ma * ma) {
+          const int i = idx / ma, j = idx - i * ma;
+          for (int r = 0; r < m; ++r) acc += N[(size_t)r * ld + oa + i] * N[(size_t)r * ld + oa + j];
+        } else {
+          const int i = idx - ma * ma;
+          for (int r = 0; r < m; ++r) acc -= N[(size_t)r * ld + oa + i] * av[r];
+        }
+        for (int c = 0; c < B.ndch; ++c) {
+          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
+          acc += A.acc[C.acc_off + off + idx];
+        }
+        out[idx] = acc;
+      }
+      off += (long long)ma * ma + ma;
+      __syncthreads();
+    }
+    if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase C: residual + quadratic form per block (spamtree_model.cpp:781-826)
+// ---------------------------------------------------------------------------------------------------------------
+struct LoglikArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const int *list;
+  int nlist;
+  const double *panels;
+  const double *w;
+  double *loglik_c;
+  int maxP, maxM;
+};
+
+__global__ __launch_bounds__(NT) void k_loglik(LoglikArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ];
+  __shared__ double s_red[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *wv = lds;
+  double *tv = wv + (A.maxP + A.maxM);
+  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
+    const int b = A.list[li];
+    const Blk B = A.blks[b];
+    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+    __syncthreads();
+    if (tid < J) {
+      const int a = A.anc_idx[B.anc_ptr + tid];
+      s_am[tid] = A.blks[a].m;
+      s_arow[tid] = A.blks[a].row0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+      s_ao[J] = o;
+    }
+    __syncthreads();
+    for (int t = 0; t < J; ++t)
+      for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[s_arow[t] + i];
+    for (int i = tid; i < m; i += NT) wv[P + i] = A.w[B.row0 + i];
+    __syncthreads();
+    const double *N = A.panels + B.panel_off;
+    for (int i = wid; i < m; i += NT / 64) {
+      double acc = 0.0;
+      for (int k = lane; k < P; k += 64) acc += N[(size_t)i * ld + k] * wv[k];
+      acc = wave_sum(acc);
+      if (lane == 0) tv[i] = acc;
+    }
+    __syncthreads();
+    double part = 0.0;
+    for (int i = tid; i < m; i += NT) {
+      double acc = tv[i];
+      if (B.isref) {
+        for (int j = 0; j <= i; ++j) acc += N[(size_t)i * ld + P + j] * wv[P + j];
+      } else {
+        acc += N[(size_t)i * ld + P] * wv[P + i];
+      }
+      part += acc * acc;
+    }
+    const double wcore = block_sum(part, s_red);
+    if (tid == 0) A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
+  }
+}
+
+// fixed-shape deterministic sum of two arrays: out[0] = sum a, out[1] = sum b  (one workgroup)
+__global__ __launch_bounds__(1024) void k_sum2(const double *a, const double *b, int n, double *out) {
+  __shared__ double sa[1024], sb[1024];
+  double xa = 0.0, xb = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { xa += a[i]; xb += b[i]; }
+  sa[threadIdx.x] = xa; sb[threadIdx.x] = xb;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
+}
+
+// XB = X * Bcoeff[:, mv]   (spamtree_model.cpp:127, 1382); X is column-major n x p in device row order
+__global__ void k_xb(const double *X, const int *mv, const double *B, long long n, int p, double *xb) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double *bj = B + (size_t)p * mv[i];
+  double acc = 0.0;
+  for (int j = 0; j < p; ++j) acc += X[(size_t)j * n + i] * bj[j];
+  xb[i] = acc;
+}
+
+// partial sums for beta / tausq: per workgroup nq = p*q + q values; stage 2 reduces in workgroup order.
+#define STATS_WG 1024
+__global__ __launch_bounds__(NT) void k_stats(const double *X, const double *y, const double *w, const double *xb, const int *mv,
+                                               const unsigned char *obs, const long long *partner, long long n, int p, int q,
+                                               double *partial) {
+  __shared__ double s_red[NT / 64];
+  const int nq = p * q + q;
+  double acc[QMAX * 8 + QMAX];  // p <= 8 enforced on the host for this kernel
+  for (int k = 0; k < nq; ++k) acc[k] = 0.0;
+  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+  for (long long i = lo + threadIdx.x; i < hi; i += NT) {
+    if (!obs[i]) continue;
+    const int v = mv[i];
+    const double rw = y[i] - w[partner[i]];
+    for (int j = 0; j < p; ++j) acc[v * p + j] += X[(size_t)j * n + i] * rw;
+    const double e = y[i] - xb[i] - w[i];
+    acc[p * q + v] += e * e;
+  }
+  for (int k = 0; k < nq; ++k) {
+    const double s = block_sum(acc[k], s_red);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * nq + k] = s;
+  }
+}
+__global__ void k_stats_final(const double *partial, int nwg, int nq, double *out) {
+  const int k = threadIdx.x;
+  if (k >= nq) return;
+  double s = 0.0;
+  for (int g = 0; g < nwg; ++g) s += partial[(size_t)g * nq + k];
+  out[k] = s;
+}
+
+__global__ void k_yhat(const double *xb, const double *w, const double *noise, const int *mv, long long n, const double *tsq_inv_q,
+                       double *yhat) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) yhat[i] = xb[i] + w[i] + noise[i] / sqrt(tsq_inv_q[mv[i]]);
+}
+
+// ===============================================================================================================
+// host side
+// ===============================================================================================================
+static thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) { p = nullptr; return hipSuccess; }
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T> &v) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct LevelInfo {
+  int first = 0, count = 0;   // into lvl_list
+  int isref = 1;
+  int maxP = 0, maxM = 0, maxMa = 0, maxLd = 0;
+  bool big_factor = false, big_sample = false;
+  size_t lds_factor = 0, lds_sample = 0, lds_loglik = 0;
+  double alg_bytes_A = 0, alg_bytes_B = 0, alg_bytes_C = 0, alg_bytes_msg = 0;
+  double flops_A = 0, flops_B = 0, flops_C = 0;
+};
+
+struct st_handle_s {
+  std::string err;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int quirks = 1, force_generic = 0;
+  long long n_all = 0, n_blocks = 0;
+  int q = 1, p = 1, d = 2, n_groups = 0, n_actual_groups = 0;
+  long long n_obs = 0;
+  size_t lds_limit = 65536;
+  int sm_count = 256;
+
+  std::vector<long long> dev2model, model2dev;       // rows
+  std::vector<int> blk_model2dev;                    // blocks
+  std::vector<Blk> blks;                             // device block order
+  std::vector<int> anc_idx, dch_idx, lvl_list, pred_list, all_obs_list;
+  std::vector<LevelInfo> levels;
+  LevelInfo pred_info;
+  std::vector<double> xtx;
+  std::vector<long long> n_obs_q;
+
+  DevBuf<double> d_cx, d_cy, d_y, d_X, d_w, d_xb, d_z, d_B, d_panels[2], d_acc, d_logdet[2], d_loglik[2], d_scalars, d_partial,
+      d_stats, d_scratch, d_tmp_n, d_tsq;
+  DevBuf<int> d_mv, d_anc, d_dch, d_lvl, d_pred, d_allobs, d_err;
+  DevBuf<unsigned char> d_obs;
+  DevBuf<long long> d_dev2model, d_partner;
+  DevBuf<Blk> d_blks;
+  size_t panel_total = 0, acc_total = 0;
+  long long scratch_stride = 0;
+  int scratch_wgs = 0;
+  int slot_map[2] = {0, 1};    // logical slot (0 param, 1 alter) -> physical arena
+  double tausq_inv[QMAX];
+  std::vector<double> theta[2];
+  bool z_valid = false;
+
+  // profiling
+  bool prof = false;
+  double prof_ms[ST_N_KERNEL_FAMILIES] = {0};
+  long long prof_n[ST_N_KERNEL_FAMILIES] = {0};
+  std::vector<double> prof_level_ms;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define HCHK(h, call)                                                                                         \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                           \
+      return ST_ERR_HIP;                                                                                      \
+    }                                                                                                         \
+  } while (0)
+
+static int fail_create(st_handle_s *h, int code, const std::string &msg) {
+  g_create_error = msg;
+  if (h) {
+    st_destroy(h);
+  }
+  return code;
+}
+
+struct ProfScope {
+  st_handle_s *h;
+  int fam;
+  double *extra;
+  ProfScope(st_handle_s *h_, int fam_, double *extra_ = nullptr) : h(h_), fam(fam_), extra(extra_) {
+    if (h->prof) (void)hipEventRecord(h->ev0, h->stream);
+  }
+  ~ProfScope() {
+    if (h->prof) {
+      (void)hipEventRecord(h->ev1, h->stream);
+      (void)hipEventSynchronize(h->ev1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+      h->prof_ms[fam] += ms;
+      h->prof_n[fam] += 1;
+      if (extra) *extra = ms;
+    }
+  }
+};
+
+static size_t lds_factor_bytes(int maxP, int maxM, int maxMa, int SR, bool big) {
+  size_t dbl = (size_t)3 * (maxP + maxM) + 3 * (size_t)maxM + (size_t)SR * maxP;
+  size_t bytes = dbl * 8 + (size_t)((maxP + maxM + 1) & ~1) * 4;
+  if (!big) bytes += ((size_t)2 * maxP * maxM + (size_t)maxMa * maxM + (size_t)2 * maxM * maxM) * 8;
+  return bytes + 64;
+}
+static size_t scratch_factor_doubles(int maxP, int maxM, int maxMa) {
+  return (size_t)2 * maxP * maxM + (size_t)maxMa * maxM + (size_t)2 * maxM * maxM;
+}
+static size_t lds_sample_bytes(int maxP, int maxM, int maxLd, bool big) {
+  size_t dbl = (size_t)(maxP + maxM) + 4 * (size_t)maxM;
+  if (!big) dbl += (size_t)maxM * maxLd + (size_t)maxM * maxM;
+  return dbl * 8 + 64;
+}
+static size_t lds_loglik_bytes(int maxP, int maxM) { return ((size_t)maxP + 2 * (size_t)maxM) * 8 + 64; }
+
+extern "C" const char *st_last_error(st_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int st_destroy(st_handle h) {
+  if (!h) return ST_OK;
+  (void)hipSetDevice(h->device);
+  h->d_cx.free(); h->d_cy.free(); h->d_y.free(); h->d_X.free(); h->d_w.free(); h->d_xb.free(); h->d_z.free(); h->d_B.free();
+  h->d_panels[0].free(); h->d_panels[1].free(); h->d_acc.free();
+  for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
+  h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
+  h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
+  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return ST_OK;
+}
+
+extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle *out) {
+  if (!pb || !out) { g_create_error = "st_create: null argument"; return ST_ERR_USAGE; }
+  *out = nullptr;
+  if (pb->d != 2) { g_create_error = "only d=2 is reachable from spamtree() (R/spamtree_fit.R:58-60)"; return ST_ERR_UNSUPPORTED; }
+  if (pb->q < 1 || pb->q > QMAX) { g_create_error = "q out of range"; return ST_ERR_UNSUPPORTED; }
+  if (pb->p < 1 || pb->p > 8) { g_create_error = "p must be in 1..8"; return ST_ERR_UNSUPPORTED; }
+  if (opt && opt->world > 1) { g_create_error = "multi-GPU sharding is not wired into this entry point yet"; return ST_ERR_UNSUPPORTED; }
+  st_handle_s *h = new st_handle_s();
+  h->device = opt ? opt->device : 0;
+  h->quirks = opt ? opt->reference_quirks : 1;
+  h->force_generic = opt ? opt->force_generic : 0;
+  const long long n = pb->n_all, nb = pb->n_blocks;
+  h->n_all = n; h->n_blocks = nb; h->q = pb->q; h->p = pb->p; h->d = pb->d; h->n_groups = pb->n_groups;
+  for (int j = 0; j < QMAX; ++j) h->tausq_inv[j] = 1.0;
+
+  // ---- block census (na_study :303-313), levels (make_gibbs_groups :194-301)
+  std::vector<int> m_of(nb), obs_of(nb, 0), grp_of(nb);
+  std::vector<long long> labels(pb->block_groups, pb->block_groups + nb);
+  std::sort(labels.begin(), labels.end());
+  labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+  if ((int)labels.size() > pb->n_groups) return fail_create(h, ST_ERR_TOPOLOGY, "more levels in block_groups than entries in res_is_ref");
+  std::vector<char> row_seen(n, 0);
+  for (long long u = 0; u < nb; ++u) {
+    m_of[u] = (int)(pb->indexing_ptr[u + 1] - pb->indexing_ptr[u]);
+    grp_of[u] = (int)(std::lower_bound(labels.begin(), labels.end(), pb->block_groups[u]) - labels.begin());
+    for (long long k = pb->indexing_ptr[u]; k < pb->indexing_ptr[u + 1]; ++k) {
+      const long long r = pb->indexing_idx[k];
+      if (r < 0 || r >= n || row_seen[r]) return fail_create(h, ST_ERR_TOPOLOGY, "indexing is not a partition of the rows");
+      row_seen[r] = 1;
+      if (std::isfinite(pb->y[r])) obs_of[u]++;
+    }
+  }
+  for (long long r = 0; r < n; ++r)
+    if (!row_seen[r]) return fail_create(h, ST_ERR_TOPOLOGY, "row without a block");
+  const int G = (int)labels.size();
+  std::vector<int> grp_has_obs(G, 0);
+  for (long long u = 0; u < nb; ++u)
+    if (obs_of[u] > 0) grp_has_obs[grp_of[u]] = 1;
+  int n_actual = 0;
+  for (int g = 0; g < G; ++g) n_actual += grp_has_obs[g];
+  for (int g = 0; g < n_actual; ++g)
+    if (!grp_has_obs[g]) return fail_create(h, ST_ERR_TOPOLOGY, "an empty level precedes an observed one");
+  h->n_actual_groups = n_actual;
+
+  // ---- device block order: by (level, id); rows contiguous per block
+  std::vector<int> order(nb);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return grp_of[a] < grp_of[b]; });
+  h->blk_model2dev.assign(nb, -1);
+  for (int i = 0; i < nb; ++i) h->blk_model2dev[order[i]] = i;
+  h->dev2model.resize(n); h->model2dev.resize(n);
+  h->blks.resize(nb);
+  long long row = 0, panel_total = 0, acc_total = 0;
+  for (int i = 0; i < nb; ++i) {
+    const int u = order[i];
+    Blk &B = h->blks[i];
+    B.row0 = row; B.m = m_of[u]; B.level = grp_of[u]; B.model_id = u; B.nobs = obs_of[u];
+    for (long long k = pb->indexing_ptr[u]; k < pb->indexing_ptr[u + 1]; ++k) {
+      if (k > pb->indexing_ptr[u] && pb->indexing_idx[k] <= pb->indexing_idx[k - 1])
+        return fail_create(h, ST_ERR_TOPOLOGY, "indexing(u) must be ascending");
+      h->dev2model[row] = pb->indexing_idx[k];
+      h->model2dev[pb->indexing_idx[k]] = row;
+      ++row;
+    }
+  }
+  // ---- ancestors: chain property anc(u) = anc(last parent) + [last parent]
+  for (int i = 0; i < nb; ++i) {
+    const int u = order[i];
+    Blk &B = h->blks[i];
+    const long long p0 = pb->parents_ptr[u], p1 = pb->parents_ptr[u + 1];
+    B.nanc = (int)(p1 - p0);
+    if (B.nanc > MAXJ) return fail_create(h, ST_ERR_UNSUPPORTED, "more than ST_MAX_ANCESTORS ancestors");
+    B.anc_ptr = (int)h->anc_idx.size();
+    int P = 0;
+    for (long long k = p0; k < p1; ++k) {
+      const long long a = pb->parents_idx[k];
+      if (a < 0 || a >= nb) return fail_create(h, ST_ERR_TOPOLOGY, "parent id out of range");
+      if (k > p0 && a <= pb->parents_idx[k - 1]) return fail_create(h, ST_ERR_TOPOLOGY, "parents(u) must be ascending");
+      if (grp_of[a] >= grp_of[u]) return fail_create(h, ST_ERR_TOPOLOGY, "parent on the same or a deeper level");
+      if (pb->res_is_ref[grp_of[a]] != 1) return fail_create(h, ST_ERR_TOPOLOGY, "parent on a non-reference level");
+      if (obs_of[a] == 0) return fail_create(h, ST_ERR_TOPOLOGY, "ancestor block without observations");
+      h->anc_idx.push_back(h->blk_model2dev[a]);
+      P += m_of[a];
+    }
+    B.P = P;
+    if (B.nanc > 0) {
+      const long long last = pb->parents_idx[p1 - 1];
+      const long long q0 = pb->parents_ptr[last], q1 = pb->parents_ptr[last + 1];
+      bool ok = (q1 - q0) == (p1 - p0 - 1);
+      for (long long k = 0; ok && k < q1 - q0; ++k) ok = pb->parents_idx[q0 + k] == pb->parents_idx[p0 + k];
+      if (!ok) return fail_create(h, ST_ERR_UNSUPPORTED, "parents(u) is not parents(last parent)+[last parent] (limited_tree is not supported)");
+    }
+    const bool observed = B.nobs > 0;
+    B.isref = (observed && B.level < pb->n_groups && pb->res_is_ref[B.level] == 1) ? 1 : 0;
+    B.ld = B.P + (B.isref ? B.m : 1);
+    B.panel_off = -1; B.acc_off = 0; B.acc_len = 0;
+    if (observed) {
+      B.panel_off = panel_total;
+      panel_total += (long long)B.m * B.ld;
+    }
+  }
+  // acc layout + direct children
+  std::vector<std::vector<int>> dch(nb);
+  for (int i = 0; i < nb; ++i) {
+    Blk &B = h->blks[i];
+    if (B.nobs == 0) continue;
+    long long len = 0;
+    for (int t = 0; t < B.nanc; ++t) {
+      const int ma = h->blks[h->anc_idx[B.anc_ptr + t]].m;
+      len += (long long)ma * ma + ma;
+    }
+    if (len > INT_MAX) return fail_create(h, ST_ERR_UNSUPPORTED, "message record too large");
+    B.acc_len = (int)len;
+    B.acc_off = acc_total;
+    acc_total += len;
+    if (B.nanc > 0) dch[h->anc_idx[B.anc_ptr + B.nanc - 1]].push_back(i);
+  }
+  for (int i = 0; i < nb; ++i) {
+    Blk &B = h->blks[i];
+    B.dch_ptr = (int)h->dch_idx.size();
+    B.ndch = (int)dch[i].size();
+    if (B.ndch > 0 && !B.isref) return fail_create(h, ST_ERR_TOPOLOGY, "a non-reference block has observed children");
+    for (int c : dch[i]) h->dch_idx.push_back(c);
+  }
+  h->panel_total = (size_t)panel_total;
+  h->acc_total = (size_t)acc_total;
+
+  // ---- level lists (u_by_block_groups) and per-level launch geometry
+  hipDeviceProp_t prop;
+  if (hipSetDevice(h->device) != hipSuccess || hipGetDeviceProperties(&prop, h->device) != hipSuccess)
+    return fail_create(h, ST_ERR_HIP, "no usable HIP device (the product path has no CPU fallback)");
+  h->sm_count = prop.multiProcessorCount;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) h->lds_limit = (size_t)v;
+    if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
+  }
+  h->levels.resize(n_actual);
+  auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
+    for (int b : list) {
+      const Blk &B = h->blks[b];
+      L.maxP = std::max(L.maxP, B.P); L.maxM = std::max(L.maxM, B.m); L.maxLd = std::max(L.maxLd, B.ld);
+      for (int t = 0; t < B.nanc; ++t) L.maxMa = std::max(L.maxMa, h->blks[h->anc_idx[B.anc_ptr + t]].m);
+      // algorithmic bytes / flops, SURVEY.md section 8d
+      const double m = B.m, P = B.P, tri = P * (P + 1) / 2, rim = B.isref ? m * (m + 1) / 2 : m;
+      double trisum = 0;
+      for (int t = 0; t < B.nanc; ++t) { const double ma = h->blks[h->anc_idx[B.anc_ptr + t]].m; trisum += ma * (ma + 1) / 2; }
+      if (!is_pred) {
+        L.alg_bytes_A += (8.0 * 2 + 8) * (m + P) + (h->q > 1 ? 4 * (m + P) : 0) + 8 * tri + 8 * m * P + 8 * rim + 16;
+        L.alg_bytes_B += 8 * m * P + 8 * rim + 8 * P + 40 * m;
+        L.alg_bytes_C += 8 * m * P + 8 * rim + 8 * (m + P) + 8;
+        L.alg_bytes_msg += 2 * 8 * (P + trisum);
+        L.flops_A += 2 * m * P * P + (B.isref ? 2 * m * m * P + m * m * m : 0);
+        L.flops_B += (B.isref ? 2.0 / 3 * m * m * m : 0) + 4 * m * P;
+        for (int t = 0; t < B.nanc; ++t) { const double ma = h->blks[h->anc_idx[B.anc_ptr + t]].m; L.flops_B += 2 * ma * ma * m; }
+        L.flops_C += 2 * m * P + (B.isref ? m * m : 0);
+      }
+    }
+    L.maxMa = std::max(L.maxMa, 1);
+    const int SR = 8;
+    L.lds_factor = lds_factor_bytes(L.maxP, L.maxM, L.maxMa, SR, false);
+    L.big_factor = h->force_generic || L.lds_factor > h->lds_limit;
+    if (L.big_factor) L.lds_factor = lds_factor_bytes(L.maxP, L.maxM, L.maxMa, 4, true);
+    L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, false);
+    L.big_sample = h->force_generic || L.lds_sample > h->lds_limit;
+    if (L.big_sample) L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, true);
+    L.lds_loglik = lds_loglik_bytes(L.maxP, L.maxM);
+  };
+  for (int g = 0; g < n_actual; ++g) {
+    LevelInfo &L = h->levels[g];
+    L.first = (int)h->lvl_list.size();
+    L.isref = (int)pb->res_is_ref[g];
+    // reference order inside a level: block_names order (make_gibbs_groups :238-246); order is irrelevant on device
+    for (long long i = 0; i < nb; ++i) {
+      const long long u = pb->block_names[i] - 1;
+      if (u < 0 || u >= nb) return fail_create(h, ST_ERR_TOPOLOGY, "block_names out of range");
+      if (grp_of[u] == g && obs_of[u] > 0) h->lvl_list.push_back(h->blk_model2dev[u]);
+    }
+    L.count = (int)h->lvl_list.size() - L.first;
+    std::sort(h->lvl_list.begin() + L.first, h->lvl_list.end());
+    std::vector<int> list(h->lvl_list.begin() + L.first, h->lvl_list.end());
+    geometry(L, list, false);
+    if (L.lds_factor > h->lds_limit || L.lds_sample > h->lds_limit || L.lds_loglik > h->lds_limit)
+      return fail_create(h, ST_ERR_UNSUPPORTED, "block too large for the LDS-resident vectors");
+  }
+  for (int i = 0; i < nb; ++i) {
+    if (h->blks[i].nobs > 0) h->all_obs_list.push_back(i);
+    else {
+      if (h->blks[i].nanc == 0) return fail_create(h, ST_ERR_TOPOLOGY, "prediction block without parents");
+      h->pred_list.push_back(i);
+    }
+  }
+  geometry(h->pred_info, h->pred_list, true);
+
+  // ---- row data in device order
+  std::vector<double> cx(n), cy(n), y(n), X((size_t)n * pb->p);
+  std::vector<int> mv(n);
+  std::vector<unsigned char> obs(n);
+  h->n_obs_q.assign(pb->q, 0);
+  for (long long i = 0; i < n; ++i) {
+    const long long r = h->dev2model[i];
+    cx[i] = pb->coords[r]; cy[i] = pb->coords[n + r];
+    const long long v = pb->mv_id[r] - 1;
+    if (v < 0 || v >= pb->q) return fail_create(h, ST_ERR_USAGE, "mv_id out of range");
+    mv[i] = (int)v;
+    const bool ok = std::isfinite(pb->y[r]);
+    obs[i] = ok ? 1 : 0;
+    y[i] = ok ? pb->y[r] : 0.0;                                  // spamtree_model.cpp:146
+    if (ok) { h->n_obs_q[v]++; h->n_obs++; }
+    for (int j = 0; j < pb->p; ++j) X[(size_t)j * n + i] = pb->X[(size_t)j * n + r];
+  }
+  // Q3 partner rows (spamtree_model.cpp:1375): the t-th available row is paired with w[t]
+  std::vector<long long> partner(n);
+  {
+    std::vector<long long> rank_av(n, -1);
+    long long t = 0;
+    for (long long r = 0; r < n; ++r)
+      if (std::isfinite(pb->y[r])) rank_av[r] = t++;
+    for (long long i = 0; i < n; ++i) {
+      const long long r = h->dev2model[i];
+      partner[i] = (h->quirks && rank_av[r] >= 0) ? h->model2dev[rank_av[r]] : i;
+    }
+  }
+  // XtX(j) over observed rows of outcome j (:151-155)
+  h->xtx.assign((size_t)pb->p * pb->p * pb->q, 0.0);
+  for (long long r = 0; r < n; ++r) {
+    if (!std::isfinite(pb->y[r])) continue;
+    const int v = (int)(pb->mv_id[r] - 1);
+    for (int a = 0; a < pb->p; ++a)
+      for (int b2 = 0; b2 < pb->p; ++b2)
+        h->xtx[(size_t)v * pb->p * pb->p + (size_t)b2 * pb->p + a] += pb->X[(size_t)a * n + r] * pb->X[(size_t)b2 * n + r];
+  }
+
+#define CCHK(call)                                                                                            \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) return fail_create(h, ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+  CCHK(hipStreamCreate(&h->stream));
+  CCHK(hipEventCreate(&h->ev0));
+  CCHK(hipEventCreate(&h->ev1));
+  CCHK(h->d_cx.upload(cx)); CCHK(h->d_cy.upload(cy)); CCHK(h->d_y.upload(y)); CCHK(h->d_X.upload(X));
+  CCHK(h->d_mv.upload(mv)); CCHK(h->d_obs.upload(obs)); CCHK(h->d_partner.upload(partner));
+  CCHK(h->d_dev2model.upload(h->dev2model));
+  CCHK(h->d_blks.upload(h->blks));
+  { std::vector<int> a = h->anc_idx; if (a.empty()) a.push_back(0); CCHK(h->d_anc.upload(a)); }
+  { std::vector<int> a = h->dch_idx; if (a.empty()) a.push_back(0); CCHK(h->d_dch.upload(a)); }
+  CCHK(h->d_lvl.upload(h->lvl_list));
+  { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
+  CCHK(h->d_allobs.upload(h->all_obs_list));
+  CCHK(h->d_w.alloc(n)); CCHK(h->d_xb.alloc(n)); CCHK(h->d_z.alloc(n)); CCHK(h->d_tmp_n.alloc(n));
+  CCHK(hipMemset(h->d_w.p, 0, n * sizeof(double)));
+  CCHK(hipMemset(h->d_xb.p, 0, n * sizeof(double)));
+  CCHK(hipMemset(h->d_z.p, 0, n * sizeof(double)));
+  CCHK(h->d_B.alloc((size_t)pb->p * pb->q));
+  CCHK(h->d_tsq.alloc(QMAX));
+  for (int s = 0; s < 2; ++s) {
+    CCHK(h->d_panels[s].alloc(h->panel_total));
+    CCHK(hipMemset(h->d_panels[s].p, 0, h->panel_total * sizeof(double)));
+    CCHK(h->d_logdet[s].alloc(nb)); CCHK(h->d_loglik[s].alloc(nb));
+    CCHK(hipMemset(h->d_logdet[s].p, 0, nb * sizeof(double)));
+    CCHK(hipMemset(h->d_loglik[s].p, 0, nb * sizeof(double)));
+  }
+  CCHK(h->d_acc.alloc(std::max<size_t>(h->acc_total, 1)));
+  CCHK(hipMemset(h->d_acc.p, 0, std::max<size_t>(h->acc_total, 1) * sizeof(double)));
+  CCHK(h->d_scalars.alloc(8));
+  CCHK(h->d_err.alloc(2));
+  CCHK(h->d_partial.alloc((size_t)STATS_WG * (pb->p * pb->q + pb->q)));
+  CCHK(h->d_stats.alloc((size_t)pb->p * pb->q + pb->q));
+  // scratch for the generic kernels: a bounded number of resident workgroups, each with its own slice
+  {
+    size_t need = 0;
+    auto upd = [&](const LevelInfo &L) {
+      if (L.big_factor) need = std::max(need, scratch_factor_doubles(L.maxP, L.maxM, L.maxMa));
+      if (L.big_sample) need = std::max(need, (size_t)L.maxM * L.maxM);
+    };
+    for (auto &L : h->levels) upd(L);
+    if (!h->pred_list.empty()) upd(h->pred_info);
+    if (need > 0) {
+      h->scratch_wgs = h->sm_count * 4;
+      h->scratch_stride = (long long)((need + 15) & ~(size_t)15);
+      CCHK(h->d_scratch.alloc((size_t)h->scratch_wgs * h->scratch_stride));
+    }
+  }
+  // opt in to > 64 KiB dynamic LDS
+  const int lim = (int)h->lds_limit;
+  (void)hipFuncSetAttribute((const void *)k_factor<false, MODE_FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor<true, MODE_FACTOR>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor<false, MODE_PREDICT>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor<true, MODE_PREDICT>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_sample<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipGetLastError();
+#undef CCHK
+  h->prof_level_ms.assign(n_actual, 0.0);
+  *out = h;
+  return ST_OK;
+}
+
+// ---- simple state accessors ---------------------------------------------------------------------------------
+static int upload_rows(st_handle h, const double *src, double *dst) {
+  std::vector<double> tmp(h->n_all);
+  for (long long i = 0; i < h->n_all; ++i) tmp[i] = src[h->dev2model[i]];
+  HCHK(h, hipMemcpyAsync(dst, tmp.data(), h->n_all * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  return ST_OK;
+}
+static int download_rows(st_handle h, const double *src, double *dst) {
+  std::vector<double> tmp(h->n_all);
+  HCHK(h, hipMemcpyAsync(tmp.data(), src, h->n_all * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  for (long long i = 0; i < h->n_all; ++i) dst[h->dev2model[i]] = tmp[i];
+  return ST_OK;
+}
+
+extern "C" int st_set_w(st_handle h, const double *w) {
+  if (!h || !w) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  return upload_rows(h, w, h->d_w.p);
+}
+extern "C" int st_get_w(st_handle h, double *w) {
+  if (!h || !w) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  return download_rows(h, h->d_w.p, w);
+}
+extern "C" int st_get_xb(st_handle h, double *xb) {
+  if (!h || !xb) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  return download_rows(h, h->d_xb.p, xb);
+}
+extern "C" int st_set_beta(st_handle h, const double *Bcoeff) {
+  if (!h || !Bcoeff) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  HCHK(h, hipMemcpyAsync(h->d_B.p, Bcoeff, (size_t)h->p * h->q * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  {
+    ProfScope ps(h, 4);
+    const int grid = (int)((h->n_all + NT - 1) / NT);
+    hipLaunchKernelGGL(k_xb, dim3(grid), dim3(NT), 0, h->stream, h->d_X.p, h->d_mv.p, h->d_B.p, h->n_all, h->p, h->d_xb.p);
+  }
+  HCHK(h, hipGetLastError());
+  HCHK(h, hipStreamSynchronize(h->stream));
+  return ST_OK;
+}
+extern "C" int st_set_tausq_inv(st_handle h, const double *t) {
+  if (!h || !t) return ST_ERR_USAGE;
+  for (int j = 0; j < h->q; ++j) h->tausq_inv[j] = t[j];
+  HCHK(h, hipSetDevice(h->device));
+  HCHK(h, hipMemcpyAsync(h->d_tsq.p, h->tausq_inv, QMAX * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  return ST_OK;
+}
+extern "C" int st_swap(st_handle h) {
+  if (!h) return ST_ERR_USAGE;
+  std::swap(h->slot_map[0], h->slot_map[1]);
+  std::swap(h->theta[0], h->theta[1]);
+  return ST_OK;
+}
+extern "C" int st_synchronize(st_handle h) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  return ST_OK;
+}
+extern "C" void *st_stream(st_handle h) { return h ? (void *)h->stream : nullptr; }
+
+// CovarianceParams::transform (covariance_functions.cpp:34-75) + vec_to_symmat (:77-92)
+static int make_covpar(st_handle h, const double *theta, int ntheta, CovPar *cp) {
+  const int q = h->q, ncb = q > 2 ? 3 : 1, npars = 3 * q + ncb, k = q * (q - 1) / 2;
+  if (ntheta != npars + k) { h->err = "theta has the wrong length"; return ST_ERR_USAGE; }
+  std::memset(cp, 0, sizeof(*cp));
+  cp->q = q; cp->ncb = ncb;
+  for (int j = 0; j < q; ++j) { cp->ai1[j] = theta[j]; cp->ai2[j] = theta[q + j]; cp->phi[j] = theta[2 * q + j]; }
+  for (int j = 0; j < ncb; ++j) cp->tmv[j] = theta[3 * q + j];
+  int ix = 0;
+  for (int j = 0; j < q; ++j)
+    for (int i = j + 1; i < q; ++i) { cp->D[i * q + j] = theta[npars + ix]; cp->D[j * q + i] = theta[npars + ix]; ++ix; }
+  return ST_OK;
+}
+
+template <bool BIG, int MODE>
+static void launch_factor(st_handle h, const LevelInfo &L, FactorArgs &A, const CovPar &cp) {
+  int grid = A.nlist;
+  if (BIG) {
+    grid = std::min(grid, h->scratch_wgs);
+    A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
+  }
+  hipLaunchKernelGGL((k_factor<BIG, MODE>), dim3(grid), dim3(NT), L.lds_factor, h->stream, A, cp);
+}
+
+static int reduce_loglik(st_handle h, int phys, double *loglik) {
+  {
+    ProfScope ps(h, 3);
+    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(1024), 0, h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p);
+  }
+  HCHK(h, hipGetLastError());
+  double s[2];
+  HCHK(h, hipMemcpyAsync(s, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  *loglik = s[0] + s[1];   // loglik_w = logdetCi + sum(loglik_w_comps)  (:987-988, :815-816)
+  return ST_OK;
+}
+
+static int read_err(st_handle h, int *code) {
+  int e[2];
+  HCHK(h, hipMemcpyAsync(e, h->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  *code = (e[0] == INT_MAX) ? 0 : (e[0] & 15);
+  return ST_OK;
+}
+static int reset_err(st_handle h) {
+  const int init[2] = {INT_MAX, 0};
+  HCHK(h, hipMemcpyAsync(h->d_err.p, init, 2 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  return ST_OK;
+}
+
+extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik) {
+  if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  CovPar cp;
+  int rc = make_covpar(h, theta, ntheta, &cp);
+  if (rc) return rc;
+  h->theta[slot].assign(theta, theta + ntheta);
+  const int phys = h->slot_map[slot];
+  rc = reset_err(h);
+  if (rc) return rc;
+  for (int g = 0; g < h->n_actual_groups; ++g) {
+    const LevelInfo &L = h->levels[g];
+    FactorArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_lvl.p + L.first; A.nlist = L.count;
+    A.cx = h->d_cx.p; A.cy = h->d_cy.p; A.mv = h->d_mv.p; A.w_in = h->d_w.p; A.w_out = nullptr; A.z = nullptr;
+    A.panels = h->d_panels[phys].p; A.logdet_c = h->d_logdet[phys].p; A.loglik_c = h->d_loglik[phys].p;
+    A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
+    {
+      ProfScope ps(h, 0, h->prof ? &h->prof_level_ms[g] : nullptr);
+      if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
+      else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
+    }
+    HCHK(h, hipGetLastError());
+  }
+  int code = 0;
+  rc = read_err(h, &code);
+  if (rc) return rc;
+  if (code) return code;  // the reference's `return false` (:971-982); deeper levels hold unspecified values (Q5)
+  double ll = 0.0;
+  rc = reduce_loglik(h, phys, &ll);
+  if (rc) return rc;
+  if (loglik) *loglik = ll;
+  return ST_OK;
+}
+
+static int gen_or_upload_z(st_handle h, const double *z, uint64_t seed, uint32_t iter, unsigned stream_id, double *dst) {
+  if (z) return upload_rows(h, z, dst);
+  {
+    ProfScope ps(h, 5);
+    const int grid = (int)((h->n_all + NT - 1) / NT);
+    hipLaunchKernelGGL(k_normals, dim3(grid), dim3(NT), 0, h->stream, dst, h->d_dev2model.p, h->n_all, iter, stream_id,
+                       (unsigned long long)seed);
+  }
+  HCHK(h, hipGetLastError());
+  return ST_OK;
+}
+
+extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  int rc = gen_or_upload_z(h, z, seed, iter, 0u, h->d_z.p);
+  if (rc) return rc;
+  h->z_valid = true;
+  rc = reset_err(h);
+  if (rc) return rc;
+  const int phys = h->slot_map[0];
+  for (int g = h->n_actual_groups - 1; g >= 0; --g) {
+    const LevelInfo &L = h->levels[g];
+    SampleArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.dch_idx = h->d_dch.p; A.list = h->d_lvl.p + L.first; A.nlist = L.count;
+    A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.y = h->d_y.p; A.xb = h->d_xb.p; A.z = h->d_z.p; A.mv = h->d_mv.p;
+    A.obs = h->d_obs.p; A.acc = h->d_acc.p; A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxLd = L.maxLd;
+    for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
+    {
+      ProfScope ps(h, 1);
+      if (L.big_sample) {
+        A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
+        hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.count, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
+      } else {
+        hipLaunchKernelGGL((k_sample<false>), dim3(L.count), dim3(NT), L.lds_sample, h->stream, A);
+      }
+    }
+    HCHK(h, hipGetLastError());
+  }
+  int code = 0;
+  rc = read_err(h, &code);
+  if (rc) return rc;
+  return code;  // 10 / 11: the reference stops with "Error at gibbs_sample_w" (:1215-1217)
+}
+
+extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {
+  if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  const int phys = h->slot_map[slot];
+  int maxP = 0, maxM = 0;
+  for (auto &L : h->levels) { maxP = std::max(maxP, L.maxP); maxM = std::max(maxM, L.maxM); }
+  const size_t lds = lds_loglik_bytes(maxP, maxM);
+  LoglikArgs A;
+  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_allobs.p; A.nlist = (int)h->all_obs_list.size();
+  A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.loglik_c = h->d_loglik[phys].p; A.maxP = maxP; A.maxM = maxM;
+  {
+    ProfScope ps(h, 2);
+    hipLaunchKernelGGL(k_loglik, dim3(A.nlist), dim3(NT), lds, h->stream, A);
+  }
+  HCHK(h, hipGetLastError());
+  double ll = 0.0;
+  int rc = reduce_loglik(h, phys, &ll);
+  if (rc) return rc;
+  if (loglik) *loglik = ll;
+  return ST_OK;
+}
+
+extern "C" int st_predict(st_handle h, int theta_changed) {
+  (void)theta_changed;  // H of a prediction block is rebuilt from the ancestor chain every call: same values as the cache
+  if (!h) return ST_ERR_USAGE;
+  if (h->pred_list.empty()) return ST_OK;
+  if (!h->z_valid) { h->err = "st_predict needs the normals of a preceding st_sample_w (spamtree_model.cpp:1325)"; return ST_ERR_USAGE; }
+  if (h->theta[0].empty()) { h->err = "st_predict before st_factor(slot 0)"; return ST_ERR_USAGE; }
+  HCHK(h, hipSetDevice(h->device));
+  CovPar cp;
+  int rc = make_covpar(h, h->theta[0].data(), (int)h->theta[0].size(), &cp);
+  if (rc) return rc;
+  const LevelInfo &L = h->pred_info;
+  FactorArgs A;
+  std::memset(&A, 0, sizeof(A));
+  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_pred.p; A.nlist = (int)h->pred_list.size();
+  A.cx = h->d_cx.p; A.cy = h->d_cy.p; A.mv = h->d_mv.p; A.w_in = h->d_w.p; A.w_out = h->d_w.p; A.z = h->d_z.p;
+  A.panels = h->d_panels[h->slot_map[0]].p; A.logdet_c = nullptr; A.loglik_c = nullptr; A.errflag = h->d_err.p;
+  A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
+  {
+    ProfScope ps(h, 6);
+    if (L.big_factor) launch_factor<true, MODE_PREDICT>(h, L, A, cp);
+    else launch_factor<false, MODE_PREDICT>(h, L, A, cp);
+  }
+  HCHK(h, hipGetLastError());
+  HCHK(h, hipStreamSynchronize(h->stream));
+  return ST_OK;
+}
+
+static int run_stats(st_handle h) {
+  const int nq = h->p * h->q + h->q;
+  {
+    ProfScope ps(h, 4);
+    hipLaunchKernelGGL(k_stats, dim3(STATS_WG), dim3(NT), 0, h->stream, h->d_X.p, h->d_y.p, h->d_w.p, h->d_xb.p, h->d_mv.p, h->d_obs.p,
+                       h->d_partner.p, h->n_all, h->p, h->q, h->d_partial.p);
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, h->stream, h->d_partial.p, STATS_WG, nq, h->d_stats.p);
+  }
+  HCHK(h, hipGetLastError());
+  return ST_OK;
+}
+extern "C" int st_beta_stats(st_handle h, double *xty) {
+  if (!h || !xty) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  int rc = run_stats(h);
+  if (rc) return rc;
+  HCHK(h, hipMemcpyAsync(xty, h->d_stats.p, (size_t)h->p * h->q * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  return ST_OK;
+}
+extern "C" int st_tausq_stats(st_handle h, double *ssq, int64_t *n_obs_by_q) {
+  if (!h || !ssq) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  int rc = run_stats(h);
+  if (rc) return rc;
+  HCHK(h, hipMemcpyAsync(ssq, h->d_stats.p + (size_t)h->p * h->q, (size_t)h->q * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  if (n_obs_by_q)
+    for (int j = 0; j < h->q; ++j) n_obs_by_q[j] = h->n_obs_q[j];
+  return ST_OK;
+}
+extern "C" int st_xtx(st_handle h, double *xtx) {
+  if (!h || !xtx) return ST_ERR_USAGE;
+  std::memcpy(xtx, h->xtx.data(), h->xtx.size() * sizeof(double));
+  return ST_OK;
+}
+
+extern "C" int st_yhat(st_handle h, const double *noise, uint64_t seed, uint32_t iter, double *yhat) {
+  if (!h || !yhat) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  int rc = gen_or_upload_z(h, noise, seed, iter, 5u, h->d_tmp_n.p);
+  if (rc) return rc;
+  const int grid = (int)((h->n_all + NT - 1) / NT);
+  hipLaunchKernelGGL(k_yhat, dim3(grid), dim3(NT), 0, h->stream, h->d_xb.p, h->d_w.p, h->d_tmp_n.p, h->d_mv.p, h->n_all, h->d_tsq.p,
+                     h->d_tmp_n.p);
+  HCHK(h, hipGetLastError());
+  return download_rows(h, h->d_tmp_n.p, yhat);
+}
+
+// ---- inspection ---------------------------------------------------------------------------------------------
+extern "C" int st_block_dims(st_handle h, int64_t u, int64_t *m, int64_t *P, int32_t *is_ref, int32_t *n_obs) {
+  if (!h || u < 0 || u >= h->n_blocks) return ST_ERR_USAGE;
+  const Blk &B = h->blks[h->blk_model2dev[u]];
+  if (m) *m = B.m;
+  if (P) *P = B.P;
+  if (is_ref) *is_ref = B.isref;
+  if (n_obs) *n_obs = B.nobs;
+  return ST_OK;
+}
+extern "C" int st_get_block(st_handle h, int slot, int64_t u, double *negRiH, double *Ri) {
+  if (!h || u < 0 || u >= h->n_blocks || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  const Blk &B = h->blks[h->blk_model2dev[u]];
+  if (B.panel_off < 0) { h->err = "block has no observations, hence no cache"; return ST_ERR_USAGE; }
+  HCHK(h, hipSetDevice(h->device));
+  std::vector<double> pan((size_t)B.m * B.ld);
+  HCHK(h, hipMemcpyAsync(pan.data(), h->d_panels[h->slot_map[slot]].p + B.panel_off, pan.size() * sizeof(double), hipMemcpyDeviceToHost,
+                         h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  if (negRiH)
+    for (int i = 0; i < B.m; ++i)
+      for (int k = 0; k < B.P; ++k) negRiH[(size_t)k * B.m + i] = pan[(size_t)i * B.ld + k];
+  if (Ri) {
+    if (B.isref) {
+      for (int i = 0; i < B.m; ++i)
+        for (int j = 0; j < B.m; ++j) Ri[(size_t)j * B.m + i] = pan[(size_t)i * B.ld + B.P + j];
+    } else {
+      for (int i = 0; i < B.m; ++i) Ri[i] = pan[(size_t)i * B.ld + B.P];
+    }
+  }
+  return ST_OK;
+}
+extern "C" int st_get_comps(st_handle h, int slot, double *logdet_c, double *loglik_c) {
+  if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  const int phys = h->slot_map[slot];
+  std::vector<double> a(h->n_blocks), b(h->n_blocks);
+  HCHK(h, hipMemcpyAsync(a.data(), h->d_logdet[phys].p, h->n_blocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipMemcpyAsync(b.data(), h->d_loglik[phys].p, h->n_blocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  for (long long i = 0; i < h->n_blocks; ++i) {
+    const int u = h->blks[i].model_id;
+    if (logdet_c) logdet_c[u] = a[i];
+    if (loglik_c) loglik_c[u] = b[i];
+  }
+  return ST_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------------------
+extern "C" int st_algorithmic_bytes(st_handle h, double *out5, double *flops3) {
+  if (!h || !out5) return ST_ERR_USAGE;
+  double a = 0, b = 0, c = 0, msg = 0, fa = 0, fb = 0, fc = 0;
+  for (auto &L : h->levels) { a += L.alg_bytes_A; b += L.alg_bytes_B; c += L.alg_bytes_C; msg += L.alg_bytes_msg; fa += L.flops_A; fb += L.flops_B; fc += L.flops_C; }
+  out5[0] = a; out5[1] = b; out5[2] = c; out5[3] = msg; out5[4] = 40.0 * (double)h->n_obs;
+  if (flops3) { flops3[0] = fa; flops3[1] = fb; flops3[2] = fc; }
+  return ST_OK;
+}
+extern "C" int st_profile_enable(st_handle h, int enable) {
+  if (!h) return ST_ERR_USAGE;
+  h->prof = enable != 0;
+  return ST_OK;
+}
+extern "C" int st_profile_get(st_handle h, double *ms_total, int64_t *launches) {
+  if (!h) return ST_ERR_USAGE;
+  for (int f = 0; f < ST_N_KERNEL_FAMILIES; ++f) {
+    if (ms_total) ms_total[f] = h->prof_ms[f];
+    if (launches) launches[f] = h->prof_n[f];
+    h->prof_ms[f] = 0; h->prof_n[f] = 0;
+  }
+  return ST_OK;
+}
+extern "C" int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, double *bytes_by_level, int32_t cap) {
+  if (!h || !n_levels) return ST_ERR_USAGE;
+  *n_levels = h->n_actual_groups;
+  for (int g = 0; g < h->n_actual_groups && g < cap; ++g) {
+    if (ms_by_level) ms_by_level[g] = h->prof_level_ms[g];
+    if (bytes_by_level) bytes_by_level[g] = h->levels[g].alg_bytes_A;
+  }
+  return ST_OK;
+}

@@ -1,0 +1,143 @@
+"""GPU parity: the HIP path (through the C-ABI) against the NumPy oracle on the same seeded inputs.
+
+Tolerances (FP64): the two sides evaluate the same formulas in different association orders (the HIP build
+works from the chain of inverse-Cholesky panels instead of the dense K_xx^{-1}); the stated bound is
+REL = 1e-9 relative to the largest magnitude of the compared array for per-block caches, log-likelihoods and
+draws of w after three sweeps.
+"""
+import numpy as np
+import pytest
+
+from tests.util import make_problem, oracle_model
+
+pytestmark = pytest.mark.gpu
+REL = 1e-9
+
+
+def hip_model(pb, theta=None, beta=None, tausq=0.1, w=None, **kw):
+    from spamtree_amd.model import SpamTreeMV
+    theta = pb["theta"] if theta is None else theta
+    beta = np.zeros(pb["p"]) if beta is None else beta
+    w = np.zeros(pb["n"]) if w is None else w
+    return SpamTreeMV(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"],
+                      pb["res_is_ref"], pb["parents"], pb["children"], False, pb["block_names"],
+                      pb["block_groups"], pb["indexing"], w, beta, theta, 1.0 / tausq, **kw)
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+
+
+CASES = [
+    dict(side=25, q=1, missing=0.0),
+    dict(side=25, q=1, missing=0.12),
+    dict(side=40, q=1, missing=0.0, random_coords=True),
+    dict(side=16, q=2, missing=0.0),
+    dict(side=14, q=3, missing=0.2),
+    dict(side=25, q=1, missing=0.0, last_not_reference=False),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("generic", [False, True])
+def test_factor_sample_loglik_predict_match_oracle(case, generic):
+    pb = make_problem(seed=17, **case)
+    rng = np.random.default_rng(5)
+    w0 = rng.standard_normal(pb["n"])
+    beta = np.array([0.3, -0.2, 0.1])
+    om = oracle_model(pb, w=w0, beta=beta, tausq=0.2)
+    hm = hip_model(pb, w=w0, beta=beta, tausq=0.2, force_generic=generic)
+    # ---- phase A on both slots
+    assert om.get_loglik_comps_w(om.param_data)
+    assert hm.get_loglik_comps_w(0)
+    assert abs(hm.loglik_w[0] - om.param_data.loglik_w) <= REL * abs(om.param_data.loglik_w)
+    ld, ll = hm.comps(0)
+    assert relerr(ld, om.param_data.logdetCi_comps) <= REL
+    assert relerr(ll, om.param_data.loglik_w_comps) <= REL
+    for u in range(om.n_blocks):
+        if om.block_ct_obs[u] == 0:
+            continue
+        H, Ri = hm.block(0, u)
+        if om.parents[u].size:
+            assert relerr(H, om.param_data.w_cond_mean_K[u]) <= 1e-8, u
+        if om.block_is_reference[u]:
+            assert relerr(Ri, om.param_data.Rcc_invchol[u]) <= REL, u
+        else:
+            assert relerr(Ri, om.param_data.ccholprecdiag[u]) <= REL, u
+    # ---- three sweeps + loglik + stats
+    for it in range(3):
+        z = rng.standard_normal(pb["n"])
+        om.gibbs_sample_w(z)
+        hm.deal_with_w(z)
+        assert relerr(hm.get_w()[om.na_ix_all], om.w[om.na_ix_all]) <= REL, it
+        om.get_loglik_w(om.param_data)
+        assert abs(hm.get_loglik_w(0) - om.param_data.loglik_w) <= REL * abs(om.param_data.loglik_w)
+        xty, ssq = hm.stats()
+        oxty, ossq = om.beta_tausq_stats()
+        assert relerr(xty, oxty) <= REL and relerr(ssq, ossq) <= REL
+    # ---- prediction at the NA blocks (reuses the last sweep's normals)
+    om.predict(True)
+    hm.predict(True)
+    assert relerr(hm.get_w(), om.w) <= REL
+    # ---- beta / tausq conjugate updates fed with the same draws
+    nb = [rng.standard_normal(pb["p"]) for _ in range(pb["q"])]
+    om.gibbs_sample_tausq(lambda j, a, b: a * b)
+    hm.gibbs_sample_tausq(lambda j, a, b: a * b)
+    assert relerr(hm.tausq_inv, om.tausq_inv) <= REL
+    om.gibbs_sample_beta(nb)
+    hm.gibbs_sample_beta(nb)
+    assert relerr(hm.Bcoeff, om.Bcoeff) <= REL
+    assert relerr(hm.get_XB(), om.XB) <= REL
+    # ---- a proposal on the other slot, accept, sweep again
+    th2 = pb["theta"] * (1.0 + 0.05 * rng.standard_normal(pb["theta"].size))
+    om.theta_update(om.alter_data, th2)
+    hm.theta_update(1, th2)
+    assert om.get_loglik_comps_w(om.alter_data) and hm.get_loglik_comps_w(1)
+    assert abs(hm.loglik_w[1] - om.alter_data.loglik_w) <= REL * abs(om.alter_data.loglik_w)
+    om.accept_make_change()
+    hm.accept_make_change()
+    z = rng.standard_normal(pb["n"])
+    om.gibbs_sample_w(z)
+    hm.deal_with_w(z)
+    assert relerr(hm.get_w()[om.na_ix_all], om.w[om.na_ix_all]) <= REL
+    hm.close()
+
+
+def test_cholesky_failure_codes():
+    pb = make_problem(side=25, q=1, seed=2)
+    th = pb["theta"].copy()
+    th[0] = -1.0
+    hm = hip_model(pb, theta=th)
+    assert hm.get_loglik_comps_w(0) is False and hm.last_errtype == 1
+    hm.theta_update(0, pb["theta"])
+    assert hm.get_loglik_comps_w(0) is True
+    hm.close()
+
+
+def test_device_normals_match_oracle_stream():
+    from oracle.spamtree_oracle import StRng
+    pb = make_problem(side=25, q=1, seed=2)
+    hm = hip_model(pb, tausq=1e-12)          # tausq_inv huge: w ~ y - XB + tiny noise is NOT what we test; see below
+    hm.close()
+    # direct check through yhat: XB = 0, w = 0, tausq_inv = 1  ->  yhat = normal(stream 5)
+    hm = hip_model(pb, tausq=1.0)
+    got = hm.yhat(None, seed=2021, it=7)
+    exp = StRng(2021).yhat_normals(7, pb["n"])
+    assert np.abs(got - exp).max() < 1e-13
+    hm.close()
+
+
+def test_generated_sweep_normals_are_the_documented_stream():
+    from oracle.spamtree_oracle import StRng
+    pb = make_problem(side=25, q=1, seed=4)
+    om = oracle_model(pb, tausq=0.3)
+    hm = hip_model(pb, tausq=0.3)
+    assert om.get_loglik_comps_w(om.param_data) and hm.get_loglik_comps_w(0)
+    om.gibbs_sample_w(StRng(77).sweep_normals(3, pb["n"]))
+    hm.deal_with_w(None, seed=77, it=3)
+    assert relerr(hm.get_w(), om.w) <= REL
+    hm.close()
