@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- Gibbs iterations/s of the HIP hot path on the n=1e6 univariate grid (BASELINE.json metric).
+
+One "step" = one body of the reference's MCMC loop (/root/reference/src/spamtree_fit.cpp:167-391) with all four
+samplers on, no prediction, no saving: w sweep (B) + w log-density (C) + Metropolis proposal for theta, i.e. a
+full re-factorisation of the proposal slot (A) + tausq and beta conjugate draws (S1, S2).
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def reference_cost(wl):
+    """Flops of the reference algorithm AS WRITTEN per iteration (BASELINE.md section 4 cost law): dense
+    (P+m)^3 Gram of the extended inverse Cholesky for blocks with children, H = Kxc' Kxx_inv (2mP^2),
+    G = A_u H (2mP^2), Schur complement and m x m factorisations."""
+    ip, pp, pidx = wl["indexing"][0], wl["parents"][0], wl["parents"][1]
+    cp = wl["children"][0]
+    m = np.diff(ip).astype(np.float64)
+    P = np.array([m[pidx[pp[u]:pp[u + 1]]].sum() for u in range(m.size)])
+    has_ch = np.diff(cp) > 0
+    return float(np.sum(4 * m * P * P + 2 * m * m * P + m ** 3 + np.where(has_ch, (P + m) ** 3, 0.0)))
+
+
+def cpu_baseline(full_wl, side, seconds_budget=20.0):
+    """oracle/refcpu (OpenMP restatement of the reference algorithm as written, kind="port") timed on the host cores
+    on a bounded sample: full iterations (B + C + A + statistics) of a smaller grid of the same family, then scaled to
+    the n=1e6 workload with the reference's own cost law.  Allocation/page-touch of its caches is not timed."""
+    from oracle.refcpu import RefCpu
+    from spamtree_amd.synthetic import make_workload
+    cores = os.cpu_count() or 1
+    wl = make_workload(side)
+    rc = RefCpu(wl["y"], wl["X"], wl["coords"], wl["mv_id"], wl["res_is_ref"], wl["parents"], wl["children"],
+                wl["block_names"], wl["block_groups"], wl["indexing"], threads=cores)
+    rc.set_tausq_inv(10.0)
+    rc.set_beta(np.zeros((wl["p"], 1)))
+    rng = np.random.default_rng(1)
+    rc.factor(0, wl["theta"])
+    its, t0 = 0, time.perf_counter()
+    while True:
+        rc.sample_w(rng.standard_normal(wl["n"]))
+        rc.loglik_w(0)
+        rc.factor(1, wl["theta"] * (1 + 0.01 * rng.standard_normal(wl["theta"].size)))
+        rc.stats()
+        its += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget or its >= 50:
+            break
+    rc.close()
+    ratio = reference_cost(wl) / reference_cost(full_wl)
+    return {"value": its / dt * ratio, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the {side}^2 grid (n={wl['n']}) in "
+                      f"{dt:.1f} s = {its / dt:.3f} it/s measured; scaled by the reference cost law "
+                      f"(sum (P+m)^3 + 4mP^2 + ...) ratio {ratio:.4f} to n={full_wl['n']}",
+            "measured_it_per_s_at_sample": its / dt, "sample_n": int(wl["n"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--side", type=int, default=1000, help="grid side; n = side^2 (1000 -> config #3, 316 -> #2)")
+    ap.add_argument("--q", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-side", type=int, default=224, help="grid side of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+
+    from spamtree_amd.mcmc import Chain
+    from spamtree_amd.model import SpamTreeMV
+    from spamtree_amd.synthetic import make_workload
+
+    t_setup = time.time()
+    wl = make_workload(args.side, q=args.q)
+    model = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
+                       wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
+                       wl["indexing"], np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"], 1.0 / 0.1, device=local_rank)
+    k = wl["theta"].size
+    chain = Chain(model, wl["bounds"], 0.01 * np.eye(k), seed=2021, adapting=True)
+    t_setup = time.time() - t_setup
+    alg = model.algorithmic_bytes()
+
+    model.profile(True)
+    for _ in range(args.warmup):
+        chain.step()
+    model.profile_get()
+    model.profile_levels()
+
+    def fence():
+        model.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chain.step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = model.profile_get()
+    lvl_ms, lvl_bytes = model.profile_levels()
+    fac_ms, fac_n = prof["factor"]
+    n_levels = max(1, len(lvl_ms))
+    avg_launch_ms = fac_ms / max(1, fac_n)
+    bytes_per_launch = alg["A"] / n_levels
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    it_s = args.steps / dt
+    out = {
+        "metric": "Gibbs iterations/sec + achieved HBM GB/s, n=1e6 grid, 1/2/4/8 MI355X",
+        "value": it_s, "unit": "Gibbs iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"config #3: n={wl['n']} ({args.side}^2 grid) q={args.q} univariate exponential "
+                               f"covariance, default tree (cell_size=25, K=(2,2)), {model.n_blocks} blocks, "
+                               "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH",
+                   "n": int(wl["n"]), "q": args.q, "blocks": int(model.n_blocks), "levels": int(n_levels),
+                   "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
+                       alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},
+        "roofline": {"bound": "hbm", "kernel": "k_factor (phase A: covariance build + chain solve + Cholesky)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "avg_launch_ms": avg_launch_ms, "launches": fac_n,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "whole_iteration_GBps": alg["total"] / (dt / args.steps) / 1e9,
+                     "by_level_ms": [round(float(x), 4) for x in lvl_ms],
+                     "by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
+                                       for b, m in zip(lvl_bytes, lvl_ms)],
+                     "phase_ms_per_iter": {kk: round(v[0] / args.steps, 4) for kk, v in prof.items()}},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(wl, args.cpu_side)
+            except Exception as exc:          # noqa: BLE001  (a missing checker must not lose the GPU line)
+                out["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(out), flush=True)
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

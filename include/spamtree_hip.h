@@ -123,12 +123,13 @@ int st_get_comps(st_handle h, int slot, double *logdetCi_comps, double *loglik_w
 /* ---- measurement: algorithmic bytes of one iteration (SURVEY.md section 8d operand-streaming model)
  * out[0..4] = phase A, B, C, messages, S1+S2;  flops[0..2] = A, B, C (may be NULL). */
 int st_algorithmic_bytes(st_handle h, double *out5, double *flops3);
-/* per-kernel-family device time, HIP events on the launch stream.  enable=1 brackets every launch with events
- * (serialises; use outside the timed region).  names: 0 factor(A) 1 sample(B) 2 loglik(C) 3 reduce 4 stats 5 rng 6 predict */
+/* per-kernel-family device time from HIP events recorded on the launch stream around every launch (enable=1);
+ * events are harvested lazily, so profiling adds no host synchronisation to the measured region.
+ * families: 0 factor(A) 1 sample(B) 2 loglik(C) 3 reduce 4 stats/xb 5 rng 6 predict */
 #define ST_N_KERNEL_FAMILIES 7
 int st_profile_enable(st_handle h, int enable);
 int st_profile_get(st_handle h, double *ms_total, int64_t *launches); /* ST_N_KERNEL_FAMILIES each; resets */
-/* per-level phase-A launch statistics of the last profiled st_factor: ms and algorithmic bytes per level */
+/* phase-A launches by tree level since the last call: mean ms per launch, algorithmic bytes per launch; resets */
 int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, double *bytes_by_level, int32_t cap);
 int st_synchronize(st_handle h);
 void *st_stream(st_handle h);                              /* the hipStream_t every kernel is launched on */

@@ -746,8 +746,11 @@ struct st_handle_s {
   bool prof = false;
   double prof_ms[ST_N_KERNEL_FAMILIES] = {0};
   long long prof_n[ST_N_KERNEL_FAMILIES] = {0};
-  std::vector<double> prof_level_ms;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<double> prof_level_ms;   // phase-A time per level, accumulated
+  std::vector<long long> prof_level_n;
+  struct ProfRec { hipEvent_t a, b; int fam, level; };
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> ev_free;
 };
 
 #define HCHK(h, call)                                                                                         \
@@ -767,22 +770,38 @@ static int fail_create(st_handle_s *h, int code, const std::string &msg) {
   return code;
 }
 
+// Launch timing with HIP events on the launch stream, harvested lazily (no host sync inside the measured region).
+static hipEvent_t prof_event(st_handle_s *h) {
+  if (!h->ev_free.empty()) { hipEvent_t e = h->ev_free.back(); h->ev_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+static void prof_harvest(st_handle_s *h) {
+  for (auto &r : h->prof_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      h->prof_ms[r.fam] += ms;
+      h->prof_n[r.fam] += 1;
+      if (r.level >= 0 && r.level < (int)h->prof_level_ms.size()) { h->prof_level_ms[r.level] += ms; h->prof_level_n[r.level] += 1; }
+    }
+    h->ev_free.push_back(r.a);
+    h->ev_free.push_back(r.b);
+  }
+  h->prof_pending.clear();
+}
 struct ProfScope {
   st_handle_s *h;
-  int fam;
-  double *extra;
-  ProfScope(st_handle_s *h_, int fam_, double *extra_ = nullptr) : h(h_), fam(fam_), extra(extra_) {
-    if (h->prof) (void)hipEventRecord(h->ev0, h->stream);
+  st_handle_s::ProfRec r;
+  ProfScope(st_handle_s *h_, int fam, int level = -1) : h(h_) {
+    r.fam = fam; r.level = level; r.a = r.b = nullptr;
+    if (h->prof) { r.a = prof_event(h); r.b = prof_event(h); (void)hipEventRecord(r.a, h->stream); }
   }
   ~ProfScope() {
-    if (h->prof) {
-      (void)hipEventRecord(h->ev1, h->stream);
-      (void)hipEventSynchronize(h->ev1);
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
-      h->prof_ms[fam] += ms;
-      h->prof_n[fam] += 1;
-      if (extra) *extra = ms;
+    if (h->prof && r.a && r.b) {
+      (void)hipEventRecord(r.b, h->stream);
+      h->prof_pending.push_back(r);
+      if (h->prof_pending.size() > 8192) prof_harvest(h);
     }
   }
 };
@@ -814,8 +833,8 @@ extern "C" int st_destroy(st_handle h) {
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
   h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free();
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  prof_harvest(h);
+  for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ST_OK;
@@ -1060,8 +1079,6 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
     if (e_ != hipSuccess) return fail_create(h, ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
   CCHK(hipStreamCreate(&h->stream));
-  CCHK(hipEventCreate(&h->ev0));
-  CCHK(hipEventCreate(&h->ev1));
   CCHK(h->d_cx.upload(cx)); CCHK(h->d_cy.upload(cy)); CCHK(h->d_y.upload(y)); CCHK(h->d_X.upload(X));
   CCHK(h->d_mv.upload(mv)); CCHK(h->d_obs.upload(obs)); CCHK(h->d_partner.upload(partner));
   CCHK(h->d_dev2model.upload(h->dev2model));
@@ -1117,6 +1134,7 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   (void)hipGetLastError();
 #undef CCHK
   h->prof_level_ms.assign(n_actual, 0.0);
+  h->prof_level_n.assign(n_actual, 0);
   *out = h;
   return ST_OK;
 }
@@ -1256,7 +1274,7 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
     A.panels = h->d_panels[phys].p; A.logdet_c = h->d_logdet[phys].p; A.loglik_c = h->d_loglik[phys].p;
     A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
     {
-      ProfScope ps(h, 0, h->prof ? &h->prof_level_ms[g] : nullptr);
+      ProfScope ps(h, 0, g);
       if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
       else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
     }
@@ -1481,6 +1499,8 @@ extern "C" int st_profile_enable(st_handle h, int enable) {
 }
 extern "C" int st_profile_get(st_handle h, double *ms_total, int64_t *launches) {
   if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  prof_harvest(h);
   for (int f = 0; f < ST_N_KERNEL_FAMILIES; ++f) {
     if (ms_total) ms_total[f] = h->prof_ms[f];
     if (launches) launches[f] = h->prof_n[f];
@@ -1490,10 +1510,13 @@ extern "C" int st_profile_get(st_handle h, double *ms_total, int64_t *launches) 
 }
 extern "C" int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, double *bytes_by_level, int32_t cap) {
   if (!h || !n_levels) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  prof_harvest(h);
   *n_levels = h->n_actual_groups;
   for (int g = 0; g < h->n_actual_groups && g < cap; ++g) {
-    if (ms_by_level) ms_by_level[g] = h->prof_level_ms[g];
+    if (ms_by_level) ms_by_level[g] = h->prof_level_n[g] ? h->prof_level_ms[g] / (double)h->prof_level_n[g] : 0.0;  // mean per launch
     if (bytes_by_level) bytes_by_level[g] = h->levels[g].alg_bytes_A;
+    h->prof_level_ms[g] = 0.0; h->prof_level_n[g] = 0;
   }
   return ST_OK;
 }
