@@ -361,6 +361,321 @@ __global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase A, fast path: one workgroup (4 waves) per COLUMN GROUP = one reference block, or several sibling
+// non-reference blocks (same ancestor chain), M <= 32 columns, chain P <= 256.  All dense contractions run on the
+// FP64 matrix cores (v_mfma_f64_16x16x4_f64: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C[(l>>4)+4r][l&15]):
+//   per ancestor panel (last to first), in sub-panels of <= 16 rows staged in LDS:
+//     V_sub = Linv_sub * K[0:Kb, :]          16 x 32 tile pair, K split over the two wave pairs
+//     T^T[0:Kb, :] += Linv_sub^T * V_sub      accumulators stay in registers (<= 8 tiles of 16x16 per wave);
+//                                             the V tile in C layout IS the B operand of this product
+//   epilogue: R = K_uu - V'V (MFMA), Cholesky + inverse in LDS, panel_u = [-Ri*T | Ri] (MFMA), log-density terms.
+// K/V live in LDS as KV[k][ldKV]; T^T is dumped into the same buffer for the epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Grp {
+  long long row0;  // first device row of the group's columns
+  int blk0, nblk;  // device blocks blk0 .. blk0+nblk-1 (siblings)
+  int M, P;
+};
+
+struct FastArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const Grp *grps;
+  int ngrp;
+  const double *cx, *cy;
+  const int *mv;
+  const double *w;
+  double *panels;
+  double *logdet_c, *loglik_c;
+  int *errflag;
+  int Pm4, ldKV, ldS, SRm, stage_dbl;
+};
+
+#define FM_VPART 512
+
+__global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
+  __shared__ int s_fail;
+  __shared__ double s_red[NT / 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int jt = wid & 1, kh = wid >> 1;
+  const int Pm4 = A.Pm4, ldKV = A.ldKV, ldS = A.ldS, SRm = A.SRm;
+  double *KV = lds;
+  double *stage = KV + (size_t)Pm4 * ldKV + 16;
+  double *Vpart = stage + A.stage_dbl;
+  double *colx = Vpart + FM_VPART, *coly = colx + 32, *colw = coly + 32, *hv = colw + 32, *rd = hv + 32;
+  int *colmv = (int *)(rd + 32);
+  int *colblk = colmv + 32;
+
+  const Grp G = A.grps[blockIdx.x];
+  const int M = G.M, P = G.P;
+  const Blk B0 = A.blks[G.blk0];
+  const int J = B0.nanc;
+  if (tid < J) {
+    const int a = A.anc_idx[B0.anc_ptr + tid];
+    s_am[tid] = A.blks[a].m;
+    s_arow[tid] = A.blks[a].row0;
+    s_apan[tid] = A.blks[a].panel_off;
+  }
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+    s_ao[J] = o;
+  }
+  __syncthreads();
+  // ---- prologue: coordinates (ancestors alias the stage area), K_{pa,u} into KV, pads zeroed
+  {
+    double *sx = stage, *sy = stage + Pm4;
+    int *smv = (int *)(stage + 2 * (size_t)Pm4);
+    for (int t = 0; t < J; ++t) {
+      const long long r0 = s_arow[t];
+      const int oa = s_ao[t];
+      for (int i = tid; i < s_am[t]; i += NT) { sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; }
+    }
+    if (tid < 32) {
+      const int j = tid;
+      if (j < M) {
+        const long long r = G.row0 + j;
+        colx[j] = A.cx[r]; coly[j] = A.cy[r]; colw[j] = A.w[r]; colmv[j] = A.mv[r];
+        int bi = 0;
+        while (bi + 1 < G.nblk && r >= A.blks[G.blk0 + bi + 1].row0) ++bi;
+        colblk[j] = bi;
+      } else {
+        colx[j] = 0.0; coly[j] = 0.0; colw[j] = 0.0; colmv[j] = 0; colblk[j] = 0;
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Pm4 * ldKV + 16; idx += NT) {
+      const int k = idx / ldKV, j = idx - k * ldKV;
+      KV[idx] = (k < P && j < M) ? cov_entry(cp, sx[k], sy[k], smv[k], colx[j], coly[j], colmv[j]) : 0.0;
+    }
+  }
+  d4 acc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  // ---- one pass over the ancestor chain, last ancestor first
+  for (int t = J - 1; t >= 0; --t) {
+    const int ma = s_am[t], oa = s_ao[t], Kb = oa + ma;
+    const double *pa = A.panels + s_apan[t];
+    const int nsub = ma > 16 ? 2 : 1;
+    const int sr0 = nsub == 2 ? (ma + 1) >> 1 : ma;
+    d4 vt[2];
+    vt[0] = vt[1] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < nsub) {
+        const int r0 = s == 0 ? 0 : sr0;
+        const int sr = s == 0 ? sr0 : ma - sr0;
+        __syncthreads();  // everyone is done with the previous contents of `stage` (and with the prologue alias)
+        for (int i = wid; i < sr; i += NT / 64) {
+          const double *src = pa + (size_t)(r0 + i) * Kb;
+          double *dst = stage + (size_t)i * ldS;
+          for (int k = lane; k < Kb; k += 64) dst[k] = src[k];
+        }
+        __syncthreads();
+        // V_sub partial over this wave pair's half of K
+        const int ns = (Kb + 3) >> 2, nh = (ns + 1) >> 1;
+        const int st0 = kh ? nh : 0, st1 = kh ? ns : nh;
+        const int ia = min(l15, SRm - 1);
+        d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int st = st0; st < st1; ++st) {
+          const int k = 4 * st + l4;
+          const double av = stage[(size_t)ia * ldS + k];
+          const double a = (l15 < sr && k < Kb) ? av : 0.0;
+          const double b = KV[(size_t)k * ldKV + jt * 16 + l15];
+          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, p, 0, 0, 0);
+        }
+        if (kh == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Vpart[jt * 256 + r * 64 + lane] = p[r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[r] += Vpart[jt * 256 + r * 64 + lane];
+            Vpart[jt * 256 + r * 64 + lane] = p[r];
+          }
+        }
+        __syncthreads();
+        if (kh == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = Vpart[jt * 256 + r * 64 + lane];
+        }
+        vt[s] = p;
+        // T^T tiles (kt = kh, kh+2, ...) += Linv_sub^T * V_sub ; the V tile (C layout) is the B operand
+        const int nst = (sr + 3) >> 2;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int kt = kh + 2 * n;
+          if (kt * 16 < Kb) {
+            const int k = kt * 16 + l15;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              if (st < nst) {
+                const int i = 4 * st + l4;
+                const double av = stage[(size_t)min(i, SRm - 1) * ldS + k];
+                const double a = (i < sr && k < Kb) ? av : 0.0;
+                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, p[st], acc[n], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    // V rows of this panel replace the K rows they were computed from (later panels read only rows < oa)
+    if (kh == 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (s < nsub) {
+          const int r0 = s == 0 ? 0 : sr0;
+          const int sr = s == 0 ? sr0 : ma - sr0;
+          const int j = jt * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = l4 + 4 * r;
+            if (i < sr && j < ldKV) KV[(size_t)(oa + r0 + i) * ldKV + j] = vt[s][r];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  const bool refgrp = B0.isref != 0;
+  double *R = stage, *Ri = stage + 32 * 32;
+  if (refgrp) {
+    // ---- R = K_uu - V'V : wave -> tile (it, jt2)
+    const int it = wid >> 1, jt2 = wid & 1;
+    if (it * 16 < M && jt2 * 16 < M) {
+      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int st = 0; st < (Pm4 >> 2); ++st) {
+        const int k = 4 * st + l4;
+        const double a = KV[(size_t)k * ldKV + it * 16 + l15];
+        const double b = KV[(size_t)k * ldKV + jt2 * 16 + l15];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + l4 + 4 * r, j = jt2 * 16 + l15;
+        if (i < M && j < M)
+          R[i * M + j] = (j <= i) ? cov_entry(cp, colx[i], coly[i], colmv[i], colx[j], coly[j], colmv[j]) - c[r] : 0.0;
+      }
+    }
+    chol_lower_inplace(R, M, &s_fail);
+    tri_inverse_lower(R, Ri, M);
+  } else {
+    if (tid < M) {
+      const int j = tid;
+      double d = cov_entry(cp, colx[j], coly[j], colmv[j], colx[j], coly[j], colmv[j]);
+      for (int k = 0; k < P; ++k) { const double v = KV[(size_t)k * ldKV + j]; d -= v * v; }
+      if (!(d > 0.0)) s_fail = 1;
+      rd[j] = 1.0 / sqrt(d);
+    }
+    __syncthreads();
+  }
+  // ---- dump T^T into the KV buffer (same [k][ldKV] layout); pads zero
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const int kt = kh + 2 * n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = kt * 16 + l4 + 4 * r, j = jt * 16 + l15;
+      if (k < Pm4 && j < ldKV) KV[(size_t)k * ldKV + j] = (k < P && j < M) ? acc[n][r] : 0.0;
+    }
+  }
+  double *wpa = Vpart;  // P <= 256 <= FM_VPART
+  for (int t = 0; t < J; ++t)
+    for (int i = tid; i < s_am[t]; i += NT) wpa[s_ao[t] + i] = A.w[s_arow[t] + i];
+  __syncthreads();
+  for (int j = wid; j < M; j += NT / 64) {
+    double a = 0.0;
+    for (int k = lane; k < P; k += 64) a += KV[(size_t)k * ldKV + j] * wpa[k];
+    a = wave_sum(a);
+    if (lane == 0) hv[j] = a;
+  }
+  __syncthreads();
+
+  double wcore_part = 0.0, logdet_part = 0.0;
+  if (refgrp) {
+    double *pu = A.panels + B0.panel_off;
+    const int ld = B0.ld;
+    // ---- N = -Ri * T : tiles (it, kt), A[i][j] = -Ri[i][j] (lower), B[j][k] = T^T[k][j]
+    const int nkt = (P + 15) >> 4, nit = (M + 15) >> 4;
+    for (int tile = wid; tile < nit * nkt; tile += NT / 64) {
+      const int it = tile % nit, kt = tile / nit;
+      const int njs = (min(M, it * 16 + 16) + 3) >> 2;
+      const int i = it * 16 + l15;
+      const int krow = min(kt * 16 + l15, Pm4 - 1);
+      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int st = 0; st < njs; ++st) {
+        const int j = 4 * st + l4;
+        const double a = (i < M && j <= i) ? -Ri[i * M + j] : 0.0;
+        const double b = KV[(size_t)krow * ldKV + j];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int io = it * 16 + l4 + 4 * r, k = kt * 16 + l15;
+        if (io < M && k < P) pu[(size_t)io * ld + k] = c[r];
+      }
+    }
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      pu[(size_t)i * ld + P + j] = Ri[idx];
+    }
+    if (tid < M) {
+      const int i = tid;
+      double e = 0.0;
+      for (int j = 0; j <= i; ++j) e += Ri[i * M + j] * (colw[j] - hv[j]);
+      wcore_part = e * e;
+      logdet_part = log(Ri[i * M + i]);
+    }
+    const double wcore = block_sum(wcore_part, s_red);
+    const double logdet = block_sum(logdet_part, s_red);
+    if (tid == 0) {
+      A.logdet_c[G.blk0] = logdet;
+      A.loglik_c[G.blk0] = (double)M * HL2PI - 0.5 * wcore;
+      if (s_fail) atomicMin(A.errflag, B0.level * 16 + (J == 0 ? 1 : 2));
+    }
+  } else {
+    // non-reference rows: panel row of column j = [ -r_j * T[j][:] | r_j ] in its own block
+    for (int j = 0; j < M; ++j) {
+      const Blk Bj = A.blks[G.blk0 + colblk[j]];
+      double *prow = A.panels + Bj.panel_off + (size_t)(G.row0 + j - Bj.row0) * Bj.ld;
+      const double r = rd[j];
+      for (int k = tid; k < P; k += NT) prow[k] = -r * KV[(size_t)k * ldKV + j];
+      if (tid == 0) prow[P] = r;
+    }
+    if (tid < G.nblk) {
+      const int bi = tid;
+      double wc = 0.0, ldt = 0.0;
+      int cnt = 0;
+      for (int j = 0; j < M; ++j)
+        if (colblk[j] == bi) {
+          const double e = rd[j] * (colw[j] - hv[j]);
+          wc += e * e;
+          ldt += log(rd[j]);
+          ++cnt;
+        }
+      A.logdet_c[G.blk0 + bi] = ldt;
+      A.loglik_c[G.blk0 + bi] = (double)cnt * HL2PI - 0.5 * wc;
+    }
+    if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 3);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Phase B: block-Gibbs draw of w_u + message push (spamtree_model.cpp:1011-1226), one workgroup per block.
 // ---------------------------------------------------------------------------------------------------------------
@@ -706,6 +1021,10 @@ struct LevelInfo {
   size_t lds_factor = 0, lds_sample = 0, lds_loglik = 0;
   double alg_bytes_A = 0, alg_bytes_B = 0, alg_bytes_C = 0, alg_bytes_msg = 0;
   double flops_A = 0, flops_B = 0, flops_C = 0;
+  // MFMA fast path of phase A (column groups)
+  bool fast = false;
+  int grp_first = 0, grp_count = 0, Pm4 = 0, ldKV = 2, ldS = 2, SRm = 1, stage_dbl = 0;
+  size_t lds_fast = 0;
 };
 
 struct st_handle_s {
@@ -723,6 +1042,8 @@ struct st_handle_s {
   std::vector<int> blk_model2dev;                    // blocks
   std::vector<Blk> blks;                             // device block order
   std::vector<int> anc_idx, dch_idx, lvl_list, pred_list, all_obs_list;
+  std::vector<Grp> grps;
+  DevBuf<Grp> d_grps;
   std::vector<LevelInfo> levels;
   LevelInfo pred_info;
   std::vector<double> xtx;
@@ -832,7 +1153,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free();
+  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -889,7 +1210,24 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return grp_of[a] < grp_of[b]; });
   h->blk_model2dev.assign(nb, -1);
-  for (int i = 0; i < nb; ++i) h->blk_model2dev[order[i]] = i;
+  {
+    // inside a level, blocks with the same last parent (identical ancestor chain) are made contiguous, so a
+    // workgroup can take several sibling leaf blocks as one column group
+    int i0 = 0;
+    while (i0 < nb) {
+      int i1 = i0;
+      while (i1 < nb && grp_of[order[i1]] == grp_of[order[i0]]) ++i1;
+      auto key = [&](int u) -> long long {
+        const long long p0 = pb->parents_ptr[u], p1 = pb->parents_ptr[u + 1];
+        if (p1 == p0) return -1;
+        const long long a = pb->parents_idx[p1 - 1];
+        return (a >= 0 && a < nb) ? (long long)h->blk_model2dev[a] : -1;
+      };
+      std::stable_sort(order.begin() + i0, order.begin() + i1, [&](int a, int b) { return key(a) < key(b); });
+      for (int i = i0; i < i1; ++i) h->blk_model2dev[order[i]] = i;
+      i0 = i1;
+    }
+  }
   h->dev2model.resize(n); h->model2dev.resize(n);
   h->blks.resize(nb);
   long long row = 0, panel_total = 0, acc_total = 0;
@@ -1022,6 +1360,53 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
     std::sort(h->lvl_list.begin() + L.first, h->lvl_list.end());
     std::vector<int> list(h->lvl_list.begin() + L.first, h->lvl_list.end());
     geometry(L, list, false);
+    // column groups for the MFMA path: a reference block alone, or consecutive sibling non-reference blocks
+    {
+      L.grp_first = (int)h->grps.size();
+      bool ok = !h->force_generic && L.maxP <= 256 && L.maxMa <= 32;
+      int maxM = 0, maxKb = 0, maxSub = 1;
+      size_t i = 0;
+      while (ok && i < list.size()) {
+        const Blk &B = h->blks[list[i]];
+        Grp G;
+        G.row0 = B.row0; G.blk0 = list[i]; G.nblk = 1; G.M = B.m; G.P = B.P;
+        if (B.m > 32) { ok = false; break; }
+        size_t j = i + 1;
+        if (!B.isref) {
+          const int lastp = B.nanc ? h->anc_idx[B.anc_ptr + B.nanc - 1] : -1;
+          while (j < list.size() && G.nblk < 32) {
+            const Blk &C = h->blks[list[j]];
+            const int lp = C.nanc ? h->anc_idx[C.anc_ptr + C.nanc - 1] : -1;
+            if (C.isref || lp != lastp || list[j] != list[j - 1] + 1 || G.M + C.m > 32) break;
+            G.M += C.m; G.nblk += 1; ++j;
+          }
+        }
+        maxM = std::max(maxM, G.M);
+        for (int t = 0; t < B.nanc; ++t) {
+          const int ma = h->blks[h->anc_idx[B.anc_ptr + t]].m;
+          maxSub = std::max(maxSub, ma > 16 ? (ma + 1) / 2 : ma);
+        }
+        maxKb = std::max(maxKb, B.P);
+        h->grps.push_back(G);
+        i = j;
+      }
+      L.grp_count = (int)h->grps.size() - L.grp_first;
+      if (ok) {
+        L.Pm4 = (L.maxP + 3) & ~3;
+        L.ldKV = std::max(2, (maxM + 1) & ~1);
+        int ldS = std::max(2, maxKb);
+        while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;   // 2 * odd: conflict-free A-operand reads
+        L.ldS = ldS; L.SRm = maxSub;
+        size_t st = (size_t)L.SRm * L.ldS + 16;
+        st = std::max(st, (size_t)2 * L.Pm4 + L.Pm4 / 2 + 2);   // prologue alias: ancestor x, y, outcome ids
+        st = std::max(st, (size_t)2 * 32 * 32);                   // epilogue alias: R, Ri
+        L.stage_dbl = (int)((st + 1) & ~(size_t)1);
+        L.lds_fast = ((size_t)L.Pm4 * L.ldKV + 16 + L.stage_dbl + FM_VPART + 5 * 32) * 8 + 64 * 4 + 64;
+        ok = L.lds_fast <= h->lds_limit;
+      }
+      L.fast = ok;
+      if (!ok) { h->grps.resize(L.grp_first); L.grp_count = 0; }
+    }
     if (L.lds_factor > h->lds_limit || L.lds_sample > h->lds_limit || L.lds_loglik > h->lds_limit)
       return fail_create(h, ST_ERR_UNSUPPORTED, "block too large for the LDS-resident vectors");
   }
@@ -1086,6 +1471,7 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   { std::vector<int> a = h->anc_idx; if (a.empty()) a.push_back(0); CCHK(h->d_anc.upload(a)); }
   { std::vector<int> a = h->dch_idx; if (a.empty()) a.push_back(0); CCHK(h->d_dch.upload(a)); }
   CCHK(h->d_lvl.upload(h->lvl_list));
+  { std::vector<Grp> g = h->grps; if (g.empty()) g.push_back(Grp{0, 0, 0, 0, 0}); CCHK(h->d_grps.upload(g)); }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
   CCHK(h->d_w.alloc(n)); CCHK(h->d_xb.alloc(n)); CCHK(h->d_z.alloc(n)); CCHK(h->d_tmp_n.alloc(n));
@@ -1131,6 +1517,7 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   (void)hipFuncSetAttribute((const void *)k_sample<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipGetLastError();
 #undef CCHK
   h->prof_level_ms.assign(n_actual, 0.0);
@@ -1275,7 +1662,15 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
     A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
     {
       ProfScope ps(h, 0, g);
-      if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
+      if (L.fast) {
+        FastArgs F;
+        std::memset(&F, 0, sizeof(F));
+        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first; F.ngrp = L.grp_count;
+        F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
+        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p;
+        F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
+        hipLaunchKernelGGL(k_factor_mfma, dim3(L.grp_count), dim3(NT), L.lds_fast, h->stream, F, cp);
+      } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
       else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
     }
     HCHK(h, hipGetLastError());
