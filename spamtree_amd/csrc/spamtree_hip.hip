@@ -373,7 +373,77 @@ __global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
 //   epilogue: R = K_uu - V'V (MFMA), Cholesky + inverse in LDS, panel_u = [-Ri*T | Ri] (MFMA), log-density terms.
 // K/V live in LDS as KV[k][ldKV]; T^T is dumped into the same buffer for the epilogue.
 // ---------------------------------------------------------------------------------------------------------------
+
+// Cholesky + triangular inverse of an m x m (m <= 32) SPD matrix by ONE wave, entirely in registers: lane i owns
+// row i (identity-padded to 32), wave-uniform elements are broadcast with v_readlane (their indices are
+// compile-time constants after unrolling).  R: LDS, row-major m x m, lower triangle valid.  Ri (LDS, m x m) receives
+// chol(R)^{-1} with zeros above the diagonal.  *fail is set on a non-positive pivot (dpotrf's test).
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+__device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fail, int lane) {
+  double a[32];
+  const int li = min(lane, m - 1);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const double v = R[li * m + min(j, m - 1)];
+    a[j] = (lane < m && j <= lane) ? v : ((j == lane) ? 1.0 : 0.0);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    if (k < m) {
+      const double dkk = readlane_f64(a[k], k);
+      bad = bad || !(dkk > 0.0);
+      const double piv = sqrt(dkk), inv = 1.0 / piv;
+      a[k] = (lane == k) ? piv : a[k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < 32; ++j) {
+        if (j < m) a[j] -= a[k] * readlane_f64(a[k], j);
+      }
+    }
+  }
+  if (bad && lane == 0) *fail = 1;
+  double x[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    double sacc = (i == lane) ? 1.0 : 0.0;
+    if (i < m) {
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc -= readlane_f64(a[k], i) * x[k];
+      sacc /= readlane_f64(a[i], i);
+    }
+    x[i] = sacc;
+  }
+  if (lane < m) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      if (i < m) Ri[i * m + lane] = (i >= lane) ? x[i] : 0.0;
+  }
+}
+
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+#ifdef FM_STAMPS
+// diagnostic build only (never shipped): per-section shader-clock totals of k_factor_mfma, thread 0 of every workgroup
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL unsigned long long st_acc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long st_t0 = clock64(), st_t1 = 0;
+#define STAMP(slot) do { st_t1 = clock64(); st_acc[slot] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
+#define STAMP_FLUSH do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); } } while (0)
+extern "C" int st_debug_stamps(unsigned long long *out, int reset) {
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define STAMP_DECL
+#define STAMP(slot) do {} while (0)
+#define STAMP_FLUSH do {} while (0)
+#endif
+
 
 struct Grp {
   long long row0;  // first device row of the group's columns
@@ -403,6 +473,8 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
   __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
   __shared__ int s_fail;
   __shared__ double s_red[NT / 64];
+  __shared__ long long s_bpan[32], s_brow[32];   // panel offset / first row of the group's blocks
+  __shared__ int s_bld[32];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -411,11 +483,20 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
   double *KV = lds;
   double *stage = KV + (size_t)Pm4 * ldKV + 16;
   double *Vpart = stage + A.stage_dbl;
+  double *zrow = Vpart - (ldS + 16);   // a row of zeros at the end of the stage area (never overwritten)
   double *colx = Vpart + FM_VPART, *coly = colx + 32, *colw = coly + 32, *hv = colw + 32, *rd = hv + 32;
   int *colmv = (int *)(rd + 32);
   int *colblk = colmv + 32;
 
-  const Grp G = A.grps[blockIdx.x];
+  STAMP_DECL
+  // workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous run of
+  // groups so that siblings, which stream the same ancestor panels, meet in one L2
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  const Grp G = A.grps[gidx];
   const int M = G.M, P = G.P;
   const Blk B0 = A.blks[G.blk0];
   const int J = B0.nanc;
@@ -424,6 +505,10 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     s_am[tid] = A.blks[a].m;
     s_arow[tid] = A.blks[a].row0;
     s_apan[tid] = A.blks[a].panel_off;
+  }
+  if (tid >= 64 && tid < 64 + G.nblk) {
+    const Blk Bb = A.blks[G.blk0 + tid - 64];
+    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
   }
   if (tid == 0) s_fail = 0;
   __syncthreads();
@@ -448,110 +533,163 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
         const long long r = G.row0 + j;
         colx[j] = A.cx[r]; coly[j] = A.cy[r]; colw[j] = A.w[r]; colmv[j] = A.mv[r];
         int bi = 0;
-        while (bi + 1 < G.nblk && r >= A.blks[G.blk0 + bi + 1].row0) ++bi;
+        while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
         colblk[j] = bi;
       } else {
         colx[j] = 0.0; coly[j] = 0.0; colw[j] = 0.0; colmv[j] = 0; colblk[j] = 0;
       }
     }
+    for (int k = tid; k < ldS + 16; k += NT) zrow[k] = 0.0;
     __syncthreads();
+    const float invld = 1.0f / (float)ldKV;
     for (int idx = tid; idx < Pm4 * ldKV + 16; idx += NT) {
-      const int k = idx / ldKV, j = idx - k * ldKV;
+      const int k = (int)(((float)idx + 0.5f) * invld), j = idx - k * ldKV;   // exact: idx < 2^14, ldKV <= 32
       KV[idx] = (k < P && j < M) ? cov_entry(cp, sx[k], sy[k], smv[k], colx[j], coly[j], colmv[j]) : 0.0;
     }
   }
   d4 acc[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) acc[n] = (d4){0.0, 0.0, 0.0, 0.0};
+  STAMP(0);
 
-  // ---- one pass over the ancestor chain, last ancestor first
-  for (int t = J - 1; t >= 0; --t) {
-    const int ma = s_am[t], oa = s_ao[t], Kb = oa + ma;
-    const double *pa = A.panels + s_apan[t];
-    const int nsub = ma > 16 ? 2 : 1;
-    const int sr0 = nsub == 2 ? (ma + 1) >> 1 : ma;
-    d4 vt[2];
-    vt[0] = vt[1] = (d4){0.0, 0.0, 0.0, 0.0};
+  // ---- one pass over the ancestor chain, last ancestor first, in sub-panels of <= 16 rows.  The next
+  // sub-panel is fetched from global memory into registers while the matrix cores work on the current one.
+  {
+    double pre[16];   // rows wid, wid+4, wid+8, wid+12 of the sub-panel x 4 chunks of 64 columns
+    auto sub_geom = [&](int t, int s, int &r0, int &sr, int &Kb) {
+      const int ma = s_am[t];
+      const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
+      r0 = s == 0 ? 0 : sr0;
+      sr = s == 0 ? sr0 : ma - sr0;
+      Kb = s_ao[t] + ma;
+    };
+    auto fetch = [&](int t, int s) {
+      int r0, sr, Kb;
+      sub_geom(t, s, r0, sr, Kb);
+      const double *src = A.panels + s_apan[t] + (size_t)(r0 + wid) * Kb + lane;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s < nsub) {
-        const int r0 = s == 0 ? 0 : sr0;
-        const int sr = s == 0 ? sr0 : ma - sr0;
-        __syncthreads();  // everyone is done with the previous contents of `stage` (and with the prologue alias)
-        for (int i = wid; i < sr; i += NT / 64) {
-          const double *src = pa + (size_t)(r0 + i) * Kb;
-          double *dst = stage + (size_t)i * ldS;
-          for (int k = lane; k < Kb; k += 64) dst[k] = src[k];
-        }
-        __syncthreads();
-        // V_sub partial over this wave pair's half of K
-        const int ns = (Kb + 3) >> 2, nh = (ns + 1) >> 1;
-        const int st0 = kh ? nh : 0, st1 = kh ? ns : nh;
-        const int ia = min(l15, SRm - 1);
-        d4 p = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int st = st0; st < st1; ++st) {
-          const int k = 4 * st + l4;
-          const double av = stage[(size_t)ia * ldS + k];
-          const double a = (l15 < sr && k < Kb) ? av : 0.0;
-          const double b = KV[(size_t)k * ldKV + jt * 16 + l15];
-          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, p, 0, 0, 0);
-        }
-        if (kh == 1) {
+      for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Vpart[jt * 256 + r * 64 + lane] = p[r];
+        for (int c = 0; c < 4; ++c) {
+#ifdef FM_NOFETCH
+          pre[rr * 4 + c] = 1e-3;
+#else
+          pre[rr * 4 + c] = (wid + 4 * rr < sr && lane + 64 * c < Kb) ? src[(size_t)(4 * rr) * Kb + 64 * c] : 0.0;
+#endif
         }
-        __syncthreads();
-        if (kh == 0) {
+      }
+    };
+    int t = J - 1, s = 0;
+    if (t >= 0) fetch(t, s);
+    d4 vt0 = (d4){0.0, 0.0, 0.0, 0.0}, vt1 = vt0;
+    while (t >= 0) {
+      const int ma = s_am[t], oa = s_ao[t];
+      const int nsub = ma > 16 ? 2 : 1;
+      int r0, sr, Kb;
+      sub_geom(t, s, r0, sr, Kb);
+      __syncthreads();  // everyone is done with the previous contents of `stage` (and with the prologue alias)
+      STAMP(1);
+      {
+        double *dst = stage + (size_t)wid * ldS + lane;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p[r] += Vpart[jt * 256 + r * 64 + lane];
-            Vpart[jt * 256 + r * 64 + lane] = p[r];
-          }
-        }
-        __syncthreads();
-        if (kh == 1) {
+        for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) p[r] = Vpart[jt * 256 + r * 64 + lane];
+          for (int c = 0; c < 4; ++c)
+            if (wid + 4 * rr < sr && lane + 64 * c < Kb) dst[(size_t)(4 * rr) * ldS + 64 * c] = pre[rr * 4 + c];
         }
-        vt[s] = p;
-        // T^T tiles (kt = kh, kh+2, ...) += Linv_sub^T * V_sub ; the V tile (C layout) is the B operand
+        if (tid < sr * 4) stage[(size_t)(tid >> 2) * ldS + Kb + (tid & 3)] = 0.0;   // k in [Kb, Kb+4) reads as zero
+      }
+      int tn = t, sn = s + 1;
+      if (sn >= nsub) { tn = t - 1; sn = 0; }
+      if (tn >= 0) fetch(tn, sn);
+      __syncthreads();
+      STAMP(2);
+      // V_sub partial over this wave pair's half of K.  Rows >= sr read the zero row, columns in [Kb, Kb+4)
+      // were zero-filled, so the loop body is two LDS reads and one MFMA.
+      const int ns = (Kb + 3) >> 2, nh = (ns + 1) >> 1;
+      const int st0 = kh ? nh : 0, st1 = kh ? ns : nh;
+      d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+      {
+        const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + 4 * st0 + l4;
+        const double *bp = KV + (size_t)(4 * st0 + l4) * ldKV + jt * 16 + l15;
+        const int bstep = 4 * ldKV;
+        int st = st0;
+        for (; st + 4 <= st1; st += 4) {
+          const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+          const double b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
+          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, p, 0, 0, 0);
+          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, p, 0, 0, 0);
+          ap += 16; bp += 4 * bstep;
+        }
+        for (; st < st1; ++st) {
+          p = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], p, 0, 0, 0);
+          ap += 4; bp += bstep;
+        }
+      }
+      STAMP(3);
+      if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vpart[jt * 256 + r * 64 + lane] = p[r];
+      }
+      __syncthreads();
+      if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] += Vpart[jt * 256 + r * 64 + lane];
+          Vpart[jt * 256 + r * 64 + lane] = p[r];
+        }
+      }
+      __syncthreads();
+      if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = Vpart[jt * 256 + r * 64 + lane];
+      }
+      if (s == 0) vt0 = p; else vt1 = p;
+      STAMP(4);
+      // T^T tiles (kt = kh, kh+2, ...) += Linv_sub^T * V_sub ; the V tile (C layout) is the B operand.
+      {
         const int nst = (sr + 3) >> 2;
+        const int kb0 = kh * 16 + l15;
+        const double *r0p = ((l4 < sr) ? stage + (size_t)l4 * ldS : zrow) + kb0;
+        const double *r1p = ((4 + l4 < sr) ? stage + (size_t)(4 + l4) * ldS : zrow) + kb0;
+        const double *r2p = ((8 + l4 < sr) ? stage + (size_t)(8 + l4) * ldS : zrow) + kb0;
+        const double *r3p = ((12 + l4 < sr) ? stage + (size_t)(12 + l4) * ldS : zrow) + kb0;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
           const int kt = kh + 2 * n;
           if (kt * 16 < Kb) {
-            const int k = kt * 16 + l15;
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-              if (st < nst) {
-                const int i = 4 * st + l4;
-                const double av = stage[(size_t)min(i, SRm - 1) * ldS + k];
-                const double a = (i < sr && k < Kb) ? av : 0.0;
-                acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, p[st], acc[n], 0, 0, 0);
-              }
-            }
+            const bool kok = kb0 + 32 * n < Kb;   // the boundary tile must not touch T columns of later panels
+            double a0 = r0p[32 * n], a1 = r1p[32 * n], a2 = r2p[32 * n], a3 = r3p[32 * n];
+            a0 = kok ? a0 : 0.0; a1 = kok ? a1 : 0.0; a2 = kok ? a2 : 0.0; a3 = kok ? a3 : 0.0;
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, p[0], acc[n], 0, 0, 0);
+            if (nst > 1) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, p[1], acc[n], 0, 0, 0);
+            if (nst > 2) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, p[2], acc[n], 0, 0, 0);
+            if (nst > 3) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, p[3], acc[n], 0, 0, 0);
           }
         }
       }
-    }
-    // V rows of this panel replace the K rows they were computed from (later panels read only rows < oa)
-    if (kh == 0) {
+      // after the panel's last sub-panel its V rows replace the K rows they were computed from
+      // (later panels read only rows < oa)
+      if (s == nsub - 1 && kh == 0) {
+        const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
+        const int j = jt * 16 + l15;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (s < nsub) {
-          const int r0 = s == 0 ? 0 : sr0;
-          const int sr = s == 0 ? sr0 : ma - sr0;
-          const int j = jt * 16 + l15;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = l4 + 4 * r;
-            if (i < sr && j < ldKV) KV[(size_t)(oa + r0 + i) * ldKV + j] = vt[s][r];
+        for (int r = 0; r < 4; ++r) {
+          const int i = l4 + 4 * r;
+          if (j < ldKV) {
+            if (i < sr0) KV[(size_t)(oa + i) * ldKV + j] = (nsub == 2) ? vt0[r] : p[r];
+            if (nsub == 2 && i < ma - sr0) KV[(size_t)(oa + sr0 + i) * ldKV + j] = vt1[r];
           }
         }
       }
+      STAMP(5);
+      t = tn; s = sn;
     }
   }
   __syncthreads();
+  STAMP(6);
 
   const bool refgrp = B0.isref != 0;
   double *R = stage, *Ri = stage + 32 * 32;
@@ -560,11 +698,12 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     const int it = wid >> 1, jt2 = wid & 1;
     if (it * 16 < M && jt2 * 16 < M) {
       d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+      const double *ap = KV + (size_t)l4 * ldKV + it * 16 + l15;
+      const double *bp = KV + (size_t)l4 * ldKV + jt2 * 16 + l15;
+      const int stp = 4 * ldKV;
       for (int st = 0; st < (Pm4 >> 2); ++st) {
-        const int k = 4 * st + l4;
-        const double a = KV[(size_t)k * ldKV + it * 16 + l15];
-        const double b = KV[(size_t)k * ldKV + jt2 * 16 + l15];
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], c, 0, 0, 0);
+        ap += stp; bp += stp;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -573,8 +712,6 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
           R[i * M + j] = (j <= i) ? cov_entry(cp, colx[i], coly[i], colmv[i], colx[j], coly[j], colmv[j]) - c[r] : 0.0;
       }
     }
-    chol_lower_inplace(R, M, &s_fail);
-    tri_inverse_lower(R, Ri, M);
   } else {
     if (tid < M) {
       const int j = tid;
@@ -583,8 +720,9 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
       if (!(d > 0.0)) s_fail = 1;
       rd[j] = 1.0 / sqrt(d);
     }
-    __syncthreads();
   }
+  __syncthreads();
+  STAMP(7);
   // ---- dump T^T into the KV buffer (same [k][ldKV] layout); pads zero
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
@@ -599,14 +737,21 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
   for (int t = 0; t < J; ++t)
     for (int i = tid; i < s_am[t]; i += NT) wpa[s_ao[t] + i] = A.w[s_arow[t] + i];
   __syncthreads();
-  for (int j = wid; j < M; j += NT / 64) {
-    double a = 0.0;
-    for (int k = lane; k < P; k += 64) a += KV[(size_t)k * ldKV + j] * wpa[k];
-    a = wave_sum(a);
-    if (lane == 0) hv[j] = a;
+  // ---- wave 0 factorises R in registers while waves 1..3 form hv = T w_pa
+  if (refgrp && wid == 0) {
+    wave_chol_inverse_32(R, M, Ri, &s_fail, lane);
+  } else {
+    const int w0 = refgrp ? wid - 1 : wid, nw = refgrp ? 3 : 4;
+    for (int j = w0; j < M; j += nw) {
+      double a = 0.0;
+      for (int k = lane; k < P; k += 64) a += KV[(size_t)k * ldKV + j] * wpa[k];
+      a = wave_sum(a);
+      if (lane == 0) hv[j] = a;
+    }
   }
   __syncthreads();
 
+  STAMP(8);
   double wcore_part = 0.0, logdet_part = 0.0;
   if (refgrp) {
     double *pu = A.panels + B0.panel_off;
@@ -651,12 +796,12 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     }
   } else {
     // non-reference rows: panel row of column j = [ -r_j * T[j][:] | r_j ] in its own block
-    for (int j = 0; j < M; ++j) {
-      const Blk Bj = A.blks[G.blk0 + colblk[j]];
-      double *prow = A.panels + Bj.panel_off + (size_t)(G.row0 + j - Bj.row0) * Bj.ld;
+    for (int j = wid; j < M; j += NT / 64) {   // one wave per column: coalesced row of the block's panel
+      const int bi = colblk[j];
+      double *prow = A.panels + s_bpan[bi] + (size_t)(G.row0 + j - s_brow[bi]) * s_bld[bi];
       const double r = rd[j];
-      for (int k = tid; k < P; k += NT) prow[k] = -r * KV[(size_t)k * ldKV + j];
-      if (tid == 0) prow[P] = r;
+      for (int k = lane; k < P; k += 64) prow[k] = -r * KV[(size_t)k * ldKV + j];
+      if (lane == 0) prow[P] = r;
     }
     if (tid < G.nblk) {
       const int bi = tid;
@@ -674,6 +819,8 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     }
     if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 3);
   }
+  STAMP(9);
+  STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1394,12 +1541,13 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
       if (ok) {
         L.Pm4 = (L.maxP + 3) & ~3;
         L.ldKV = std::max(2, (maxM + 1) & ~1);
-        int ldS = std::max(2, maxKb);
+        int ldS = std::max(2, maxKb + 4);                       // 4 zero-filled pad columns per staged row
         while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;   // 2 * odd: conflict-free A-operand reads
         L.ldS = ldS; L.SRm = maxSub;
         size_t st = (size_t)L.SRm * L.ldS + 16;
         st = std::max(st, (size_t)2 * L.Pm4 + L.Pm4 / 2 + 2);   // prologue alias: ancestor x, y, outcome ids
         st = std::max(st, (size_t)2 * 32 * 32);                   // epilogue alias: R, Ri
+        st = ((st + 1) & ~(size_t)1) + (size_t)L.ldS + 16;       // + the zero row at the end
         L.stage_dbl = (int)((st + 1) & ~(size_t)1);
         L.lds_fast = ((size_t)L.Pm4 * L.ldKV + 16 + L.stage_dbl + FM_VPART + 5 * 32) * 8 + 64 * 4 + 64;
         ok = L.lds_fast <= h->lds_limit;
