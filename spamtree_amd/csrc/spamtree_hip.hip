@@ -425,6 +425,55 @@ __device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fa
   }
 }
 
+
+// Cholesky of S (m x m, m <= 32, LDS row-major, lower triangle valid) by one wave in registers, then
+// w = L^{-T} (L^{-1} b + z): the block-Gibbs draw of spamtree_model.cpp:1054, 1086 without forming the inverse.
+__device__ void wave_chol_solve_32(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
+  double a[32];
+  const int li = min(lane, m - 1);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const double v = S[li * m + min(j, m - 1)];
+    a[j] = (lane < m && j <= lane) ? v : ((j == lane) ? 1.0 : 0.0);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    if (k < m) {
+      const double dkk = readlane_f64(a[k], k);
+      bad = bad || !(dkk > 0.0);
+      const double piv = sqrt(dkk), inv = 1.0 / piv;
+      a[k] = (lane == k) ? piv : a[k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < 32; ++j) {
+        if (j < m) a[j] -= a[k] * readlane_f64(a[k], j);
+      }
+    }
+  }
+  if (bad && lane == 0) *fail = 1;
+  double x = (lane < m) ? b[lane] : 0.0;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    if (k < m) {
+      const double xk = readlane_f64(x, k) / readlane_f64(a[k], k);
+      x = (lane == k) ? xk : ((lane > k) ? x - a[k] * xk : x);
+    }
+  }
+  x += (lane < m) ? z[lane] : 0.0;
+  double wv_ = 0.0;   // solved entries, lane i holds w_i once k <= i has been processed
+#pragma unroll
+  for (int k = 31; k >= 0; --k) {
+    if (k < m) {
+      double part = (lane > k && lane < m) ? a[k] * wv_ : 0.0;   // L[i][k] w_i, i > k
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      const double wk = (readlane_f64(x, k) - part) / readlane_f64(a[k], k);
+      wv_ = (lane == k) ? wk : wv_;
+    }
+  }
+  if (lane < m) wout[lane] = wv_;
+}
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #ifdef FM_STAMPS
@@ -1010,6 +1059,232 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, fast path: one workgroup per column group (same groups as k_factor_mfma).  A sibling group of
+// non-reference blocks is treated as ONE block with a diagonal Ri: the Gram of the stacked panel rows is the sum
+// of the siblings' messages, so the group writes one message record (at its first block) instead of one per block.
+// Gram matrices N_a' N_a run on the FP64 matrix cores; the m x m posterior Cholesky and both triangular solves
+// run in the registers of wave 0.
+// ---------------------------------------------------------------------------------------------------------------
+struct SampleFastArgs {
+  const Blk *blks;
+  const int *anc_idx, *dch_idx;
+  const Grp *grps;
+  int ngrp;
+  const double *panels;
+  double *w;
+  const double *y, *xb, *z;
+  const int *mv;
+  double *acc;
+  int *errflag;
+  int ldN, Mr4, maxP;
+  double tausq_inv[QMAX];
+};
+
+__global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32];
+  __shared__ int s_bld[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];               // message records of the direct children
+  __shared__ int s_nch;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int ldN = A.ldN, Mr4 = A.Mr4;
+  double *Np = lds;                              // Mr4 x ldN
+  double *wv = Np + (size_t)Mr4 * ldN;           // maxP + 32 : ancestors' w, then the group's new w
+  double *tv = wv + A.maxP + 32, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32;
+  double *av = zc + 32;                          // MAXJ x 32
+  double *S = av + MAXJ * 32;                    // 32 x 32
+  int *colblk = (int *)(S + 32 * 32);
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  const Grp G = A.grps[gidx];
+  const int M = G.M, P = G.P;
+  const Blk B0 = A.blks[G.blk0];
+  const int J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid < J) {
+    const int a = A.anc_idx[B0.anc_ptr + tid];
+    s_am[tid] = A.blks[a].m;
+    s_arow[tid] = A.blks[a].row0;
+  }
+  if (tid >= 64 && tid < 64 + G.nblk) {
+    const Blk Bb = A.blks[G.blk0 + tid - 64];
+    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
+  }
+  if (tid >= 128 && tid < 128 + min(B0.ndch, 64)) s_coff[tid - 128] = A.blks[A.dch_idx[B0.dch_ptr + tid - 128]].acc_off;
+  if (tid == 0) { s_fail = 0; s_nch = min(B0.ndch, 64); }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    long long ao = 0;
+    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+    s_ao[J] = o; s_aoff[J] = ao;
+  }
+  if (tid < 32) {
+    const int j = tid;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      tsq[j] = A.tausq_inv[A.mv[r]]; yx[j] = A.y[r] - A.xb[r]; zc[j] = A.z[r];
+      int bi = 0;
+      while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
+      colblk[j] = bi;
+    } else {
+      tsq[j] = 0.0; yx[j] = 0.0; zc[j] = 0.0; colblk[j] = 0;
+    }
+  }
+  __syncthreads();
+  for (int t = 0; t < J; ++t)
+    for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[s_arow[t] + i];
+  // panel rows -> LDS (row j of the group = one panel row of its block); pad rows / columns zero.
+  // Each wave takes rows wid, wid+4, ...; all loads of four rows are issued before the first LDS store.
+  const int rowlen = P + (refgrp ? M : 1);
+  for (int jb = 0; jb < Mr4; jb += 16) {
+    double tmp[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = jb + wid + 4 * rr;
+      const int jc = min(j, M - 1);
+      const int bi = colblk[jc];
+      const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = lane + 64 * c;
+        tmp[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = jb + wid + 4 * rr;
+      if (j < Mr4) {
+        double *dst = Np + (size_t)j * ldN;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k = lane + 64 * c;
+          if (k < ldN) dst[k] = tmp[rr][c];
+        }
+        for (int k = 256 + lane; k < ldN; k += 64) dst[k] = 0.0;
+      }
+    }
+  }
+  for (int j = wid; j < M; j += NT / 64) {          // rows longer than 256 columns (P + M > 256)
+    const int bi = colblk[j];
+    const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + j - s_brow[bi]) * s_bld[bi];
+    for (int k = 256 + lane; k < rowlen; k += 64) Np[(size_t)j * ldN + k] = src[k];
+  }
+  __syncthreads();
+  for (int j = wid; j < M; j += NT / 64) {
+    double a = 0.0;
+    const double *row = Np + (size_t)j * ldN;
+    for (int k = lane; k < P; k += 64) a += row[k] * wv[k];
+    a = wave_sum(a);
+    if (lane == 0) tv[j] = a;
+  }
+  __syncthreads();
+  if (refgrp) {
+    const double *Ri = Np + P;   // Ri[i][j] = Np[i*ldN + P + j]
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      double a = 0.0;
+      if (j <= i) {
+        for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
+        for (int c = 0; c < s_nch; ++c) a += A.acc[s_coff[c] + B0.acc_len + idx];
+        if (i == j) a += tsq[i];
+      }
+      S[idx] = a;
+    }
+    if (tid < M) {
+      const int i = tid;
+      double a = 0.0;
+      for (int k = i; k < M; ++k) a -= Ri[(size_t)k * ldN + i] * tv[k];
+      for (int c = 0; c < s_nch; ++c) a += A.acc[s_coff[c] + B0.acc_len + M * M + i];
+      bv[i] = a + tsq[i] * yx[i];
+    }
+    __syncthreads();
+    if (wid == 0) wave_chol_solve_32(S, M, bv, zc, wv + P, &s_fail, lane);
+    __syncthreads();
+    if (tid < M) {
+      const int i = tid;
+      A.w[G.row0 + i] = wv[P + i];
+      double a = tv[i];
+      for (int j = 0; j <= i; ++j) a += Ri[(size_t)i * ldN + j] * wv[P + j];
+      ev[i] = a;
+    }
+  } else {
+    if (tid < M) {
+      const int j = tid;
+      const double rj = Np[(size_t)j * ldN + P];
+      const double sig = rj * rj + tsq[j];
+      if (!(sig > 0.0)) s_fail = 1;
+      const double mu = -rj * tv[j] + tsq[j] * yx[j];
+      const double c = 1.0 / sqrt(sig);
+      const double wj = c * c * mu + c * zc[j];
+      wv[P + j] = wj;
+      A.w[G.row0 + j] = wj;
+      ev[j] = rj * wj + tv[j];
+    }
+  }
+  __syncthreads();
+  // av[t][r] = ev[r] - sum_j N[r][oa_t + j] w_a[j]  for every ancestor t
+  for (int idx = tid; idx < J * 32; idx += NT) {
+    const int t = idx >> 5, r = idx & 31;
+    double a = 0.0;
+    if (r < M) {
+      a = ev[r];
+      const double *row = Np + (size_t)r * ldN + s_ao[t];
+      const double *wa = wv + s_ao[t];
+      for (int j = 0; j < s_am[t]; ++j) a -= row[j] * wa[j];
+    }
+    av[idx] = a;
+  }
+  __syncthreads();
+  // message record per ancestor: [ N_a' N_a | -N_a' av_a ] + the children's records   (spamtree_model.cpp:1158-1207)
+  double *rec = A.acc + B0.acc_off;
+  const int nsteps = Mr4 >> 2;
+  for (int u = wid; u < J * 4; u += NT / 64) {
+    const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
+    const int ma = s_am[t], oa = s_ao[t];
+    if (it * 16 >= ma || jt * 16 >= ma) continue;
+    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+    const double *ap = Np + (size_t)l4 * ldN + oa + it * 16 + l15;
+    const double *bp = Np + (size_t)l4 * ldN + oa + jt * 16 + l15;
+    for (int st = 0; st < nsteps; ++st) {
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], c, 0, 0, 0);
+      ap += 4 * ldN; bp += 4 * ldN;
+    }
+    double *out = rec + s_aoff[t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+      if (i < ma && j < ma) {
+        double v = c[r];
+        for (int cc = 0; cc < s_nch; ++cc) v += A.acc[s_coff[cc] + s_aoff[t] + i * ma + j];
+        out[i * ma + j] = v;
+      }
+    }
+  }
+  for (int idx = tid; idx < J * 32; idx += NT) {
+    const int t = idx >> 5, i = idx & 31;
+    const int ma = s_am[t], oa = s_ao[t];
+    if (i < ma) {
+      double a = 0.0;
+      for (int r = 0; r < M; ++r) a -= Np[(size_t)r * ldN + oa + i] * av[t * 32 + r];
+      for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
+      rec[s_aoff[t] + ma * ma + i] = a;
+    }
+  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Phase C: residual + quadratic form per block (spamtree_model.cpp:781-826)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1172,6 +1447,8 @@ struct LevelInfo {
   bool fast = false;
   int grp_first = 0, grp_count = 0, Pm4 = 0, ldKV = 2, ldS = 2, SRm = 1, stage_dbl = 0;
   size_t lds_fast = 0;
+  int ldN = 2, Mr4 = 4;
+  size_t lds_sfast = 0;
 };
 
 struct st_handle_s {
@@ -1442,13 +1719,6 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
     acc_total += len;
     if (B.nanc > 0) dch[h->anc_idx[B.anc_ptr + B.nanc - 1]].push_back(i);
   }
-  for (int i = 0; i < nb; ++i) {
-    Blk &B = h->blks[i];
-    B.dch_ptr = (int)h->dch_idx.size();
-    B.ndch = (int)dch[i].size();
-    if (B.ndch > 0 && !B.isref) return fail_create(h, ST_ERR_TOPOLOGY, "a non-reference block has observed children");
-    for (int c : dch[i]) h->dch_idx.push_back(c);
-  }
   h->panel_total = (size_t)panel_total;
   h->acc_total = (size_t)acc_total;
 
@@ -1552,11 +1822,38 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
         L.lds_fast = ((size_t)L.Pm4 * L.ldKV + 16 + L.stage_dbl + FM_VPART + 5 * 32) * 8 + 64 * 4 + 64;
         ok = L.lds_fast <= h->lds_limit;
       }
+      if (ok) {
+        L.Mr4 = std::max(4, (maxM + 3) & ~3);
+        L.ldN = (L.maxLd + 16 + 1) | 1;   // odd stride, room for the 16-wide tile overshoot
+        L.ldN = std::max(L.ldN, L.maxP + 33);
+        const size_t dbl = (size_t)L.Mr4 * L.ldN + (size_t)L.maxP + 32 + 6 * 32 + (size_t)MAXJ * 32 + 32 * 32 + 16;
+        L.lds_sfast = dbl * 8 + 64 * 4 + 64;
+        ok = L.lds_sfast <= h->lds_limit;
+      }
       L.fast = ok;
       if (!ok) { h->grps.resize(L.grp_first); L.grp_count = 0; }
     }
     if (L.lds_factor > h->lds_limit || L.lds_sample > h->lds_limit || L.lds_loglik > h->lds_limit)
       return fail_create(h, ST_ERR_UNSUPPORTED, "block too large for the LDS-resident vectors");
+  }
+  // direct children that hold a message record: every observed block of a generic level, the first block of each
+  // column group of a fast level (the group's record is the sum over its sibling blocks)
+  {
+    std::vector<char> holder(nb, 0);
+    for (int g = 0; g < n_actual; ++g) {
+      const LevelInfo &L = h->levels[g];
+      if (L.fast) for (int k = 0; k < L.grp_count; ++k) holder[h->grps[L.grp_first + k].blk0] = 1;
+      else for (int k = 0; k < L.count; ++k) holder[h->lvl_list[L.first + k]] = 1;
+    }
+    for (int i = 0; i < nb; ++i) {
+      Blk &B = h->blks[i];
+      B.dch_ptr = (int)h->dch_idx.size();
+      B.ndch = 0;
+      if (!dch[i].empty() && !B.isref) return fail_create(h, ST_ERR_TOPOLOGY, "a non-reference block has observed children");
+      for (int c : dch[i]) if (holder[c]) { h->dch_idx.push_back(c); B.ndch++; }
+      if (B.ndch > 64 && B.nobs > 0 && h->levels[B.level].fast)
+        return fail_create(h, ST_ERR_UNSUPPORTED, "more than 64 direct child groups under one block");
+    }
   }
   for (int i = 0; i < nb; ++i) {
     if (h->blks[i].nobs > 0) h->all_obs_list.push_back(i);
@@ -1666,6 +1963,7 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipGetLastError();
 #undef CCHK
   h->prof_level_ms.assign(n_actual, 0.0);
@@ -1865,7 +2163,15 @@ extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
     {
       ProfScope ps(h, 1);
-      if (L.big_sample) {
+      if (L.fast) {
+        SampleFastArgs F;
+        std::memset(&F, 0, sizeof(F));
+        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first; F.ngrp = L.grp_count;
+        F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
+        F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.maxP = L.maxP;
+        for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
+        hipLaunchKernelGGL(k_sample_mfma, dim3(L.grp_count), dim3(NT), L.lds_sfast, h->stream, F);
+      } else if (L.big_sample) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
         hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.count, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
       } else {
