@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--side", type=int, default=1000, help="grid side; n = side^2 (1000 -> config #3, 316 -> #2)")
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-protocol", action="store_true", help="use the multi-GPU local/exchange/finish steps with 1 rank")
     ap.add_argument("--cpu-side", type=int, default=224, help="grid side of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
@@ -81,22 +82,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "--force-protocol" in sys.argv:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 
     from spamtree_amd.mcmc import Chain
-    from spamtree_amd.model import SpamTreeMV
+    from spamtree_amd.sharded import ShardedSpamTreeMV
     from spamtree_amd.synthetic import make_workload
 
     t_setup = time.time()
     wl = make_workload(args.side, q=args.q)
-    model = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
-                       wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
-                       wl["indexing"], np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"], 1.0 / 0.1, device=local_rank)
+    # one problem shared by all ranks: subtrees below a cut level are owned by one GPU, the top is replicated,
+    # exchanges are RCCL all-reduces on the library's stream (spamtree_amd/sharded.py)
+    model = ShardedSpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
+                              wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"],
+                              wl["block_groups"], wl["indexing"], np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"],
+                              1.0 / 0.1, device=local_rank, dist=dist, force_protocol=args.force_protocol)
     k = wl["theta"].size
     chain = Chain(model, wl["bounds"], 0.01 * np.eye(k), seed=2021, adapting=True)
     t_setup = time.time() - t_setup
@@ -131,7 +138,11 @@ def main():
     fac_ms, fac_n = prof["factor"]
     n_levels = max(1, len(lvl_ms))
     avg_launch_ms = fac_ms / max(1, fac_n)
-    bytes_per_launch = alg["A"] / n_levels
+    share = 1.0
+    if world > 1:
+        info = model.shard_info()
+        share = max(info["owned_rows"], 1) / float(wl["n"])        # this rank's part of the level launches (approximate)
+    bytes_per_launch = alg["A"] / n_levels * share
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     it_s = args.steps / dt
     out = {
@@ -141,7 +152,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"config #3: n={wl['n']} ({args.side}^2 grid) q={args.q} univariate exponential "
                                f"covariance, default tree (cell_size=25, K=(2,2)), {model.n_blocks} blocks, "
-                               "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH",
+                               "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH"
+                               + (f"; sharded over {world} GPUs by subtree, RCCL all-reduce exchanges" if world > 1 else ""),
                    "n": int(wl["n"]), "q": args.q, "blocks": int(model.n_blocks), "levels": int(n_levels),
                    "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
                        alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},

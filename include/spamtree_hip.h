@@ -65,7 +65,7 @@ typedef struct st_options {
   int32_t device;              /* HIP device ordinal                                                               */
   int32_t reference_quirks;    /* 1 = reproduce spamtree_model.cpp:1375 (Q3: beta uses subset positions on full w) */
   int32_t rank;                /* multi-GPU: this process' rank ...                                                */
-  int32_t world;               /* ... of `world` processes sharing one problem (1 = single GPU)                    */
+  int32_t world;               /* ... of `world` processes sharing one problem (1 = single GPU); see the end of this file */
   int32_t force_generic;       /* 1 = use the global-scratch kernels even where the LDS kernels fit (testing)      */
   int32_t reserved;
 } st_options;
@@ -133,6 +133,31 @@ int st_profile_get(st_handle h, double *ms_total, int64_t *launches); /* ST_N_KE
 int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, double *bytes_by_level, int32_t cap);
 int st_synchronize(st_handle h);
 void *st_stream(st_handle h);                              /* the hipStream_t every kernel is launched on */
+
+int st_set_stream(st_handle h, void *stream);              /* launch on the caller's stream (the one its collectives use) */
+
+/* ---- multi-GPU (st_options.world > 1): one process per GPU shares ONE problem.
+ * Ownership: whole subtrees below a cut level belong to one rank, levels above the cut are replicated
+ * (st_shard_plan is pure host code: owner[u] = rank or -1 for replicated; no GPU needed).
+ * Every exchange is an all-reduce(sum) in which each entry is contributed by exactly one rank and is zero on the
+ * others, so the result is bit-identical to the single-GPU arrays for any number of ranks.  The caller owns the
+ * collective (RCCL through torch.distributed on the stream given to st_set_stream); the single-call forms
+ * (st_factor, st_sample_w, st_loglik_w) are the world == 1 composition of the same steps.
+ *   phase A : st_factor_local -> st_mg_pack_comps -> all-reduce(buf) -> st_mg_finish        (code 0/1/2/3, loglik)
+ *   phase C : st_loglik_local -> st_mg_pack_comps -> all-reduce(buf) -> st_mg_finish
+ *   phase B : st_sample_w_local -> all-reduce(st_mg_top_region) -> st_sample_w_top
+ *             -> st_mg_pack_w -> all-reduce(buf) -> st_mg_unpack_w                           (code 0/10/11) */
+int st_shard_plan(const st_problem *pb, int32_t world, int64_t *owner /* n_blocks */, int32_t *cut_level);
+int st_shard_info(st_handle h, int32_t *rank, int32_t *world, int32_t *cut_level, int64_t *owned_blocks, int64_t *owned_rows);
+int st_factor_local(st_handle h, int slot, const double *theta, int ntheta);
+int st_loglik_local(st_handle h, int slot);
+int st_mg_pack_comps(st_handle h, int slot, void **dev_ptr, int64_t *len);
+int st_mg_finish(st_handle h, double *loglik);
+int st_sample_w_local(st_handle h, const double *z, uint64_t seed, uint32_t iter);
+int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len);
+int st_sample_w_top(st_handle h);
+int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len);
+int st_mg_unpack_w(st_handle h);
 
 #ifdef __cplusplus
 }

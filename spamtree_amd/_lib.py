@@ -51,6 +51,18 @@ SIGNATURES = {
     "st_profile_levels": (C.c_int, [H, C.POINTER(C.c_int32), c_dp, c_dp, C.c_int32]),
     "st_synchronize": (C.c_int, [H]),
     "st_stream": (C.c_void_p, [H]),
+    "st_set_stream": (C.c_int, [H, C.c_void_p]),
+    "st_shard_plan": (C.c_int, [C.POINTER(StProblem), C.c_int32, c_ip, C.POINTER(C.c_int32)]),
+    "st_shard_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_ip, c_ip]),
+    "st_factor_local": (C.c_int, [H, C.c_int, c_dp, C.c_int]),
+    "st_loglik_local": (C.c_int, [H, C.c_int]),
+    "st_mg_pack_comps": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), c_ip]),
+    "st_mg_finish": (C.c_int, [H, c_dp]),
+    "st_sample_w_local": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32]),
+    "st_mg_top_region": (C.c_int, [H, C.POINTER(C.c_void_p), c_ip]),
+    "st_sample_w_top": (C.c_int, [H]),
+    "st_mg_pack_w": (C.c_int, [H, C.POINTER(C.c_void_p), c_ip]),
+    "st_mg_unpack_w": (C.c_int, [H]),
 }
 
 _lib = None

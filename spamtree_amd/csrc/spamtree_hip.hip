@@ -1449,6 +1449,7 @@ struct LevelInfo {
   size_t lds_fast = 0;
   int ldN = 2, Mr4 = 4;
   size_t lds_sfast = 0;
+  int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
 };
 
 struct st_handle_s {
@@ -1468,6 +1469,16 @@ struct st_handle_s {
   std::vector<int> anc_idx, dch_idx, lvl_list, pred_list, all_obs_list;
   std::vector<Grp> grps;
   DevBuf<Grp> d_grps;
+  // multi-GPU sharding
+  int rank = 0, world = 1, cut = 0;
+  std::vector<int> blk_owner;                 // device block -> owning rank, -1 = replicated
+  std::vector<int> own_obs_list;              // observed blocks this rank evaluates in phase C
+  DevBuf<int> d_ownobs;
+  DevBuf<unsigned char> d_rowmask, d_blkmask; // 1 = this rank contributes the entry to a sum-with-zeros exchange
+  DevBuf<double> d_comm;                      // 2*n_blocks + 64 doubles
+  long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
+  std::vector<std::pair<long long, long long>> top_zero;   // sub-ranges of it owned by other ranks
+  bool ext_stream = false;
   std::vector<LevelInfo> levels;
   LevelInfo pred_info;
   std::vector<double> xtx;
@@ -1578,21 +1589,38 @@ extern "C" int st_destroy(st_handle h) {
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
   h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free();
+  h->d_ownobs.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && !h->ext_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ST_OK;
 }
 
+static int create_impl(const st_problem *pb, const st_options *opt, st_handle *out, bool plan_only, int64_t *owner_out, int32_t *cut_out);
+
 extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle *out) {
+  return create_impl(pb, opt, out, false, nullptr, nullptr);
+}
+
+// Pure host: which rank owns each block (0-based block id) when `world` processes share one problem; -1 = replicated
+// on every rank (the levels above the cut).  No GPU needed: lets the sharding plan be tested on CPU.
+extern "C" int st_shard_plan(const st_problem *pb, int32_t world, int64_t *owner, int32_t *cut_level) {
+  st_options opt = {0, 1, 0, world, 0, 0};
+  st_handle dummy = nullptr;
+  return create_impl(pb, &opt, &dummy, true, owner, cut_level);
+}
+
+static int create_impl(const st_problem *pb, const st_options *opt, st_handle *out, bool plan_only, int64_t *owner_out, int32_t *cut_out) {
   if (!pb || !out) { g_create_error = "st_create: null argument"; return ST_ERR_USAGE; }
   *out = nullptr;
   if (pb->d != 2) { g_create_error = "only d=2 is reachable from spamtree() (R/spamtree_fit.R:58-60)"; return ST_ERR_UNSUPPORTED; }
   if (pb->q < 1 || pb->q > QMAX) { g_create_error = "q out of range"; return ST_ERR_UNSUPPORTED; }
   if (pb->p < 1 || pb->p > 8) { g_create_error = "p must be in 1..8"; return ST_ERR_UNSUPPORTED; }
-  if (opt && opt->world > 1) { g_create_error = "multi-GPU sharding is not wired into this entry point yet"; return ST_ERR_UNSUPPORTED; }
+  if (opt && (opt->world < 1 || opt->rank < 0 || opt->rank >= opt->world || opt->world > 64)) { g_create_error = "bad rank/world"; return ST_ERR_USAGE; }
   st_handle_s *h = new st_handle_s();
+  h->rank = opt ? opt->rank : 0;
+  h->world = opt ? opt->world : 1;
   h->device = opt ? opt->device : 0;
   h->quirks = opt ? opt->reference_quirks : 1;
   h->force_generic = opt ? opt->force_generic : 0;
@@ -1721,6 +1749,53 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   }
   h->panel_total = (size_t)panel_total;
   h->acc_total = (size_t)acc_total;
+
+  // ---- multi-GPU ownership: whole subtrees below a cut level go to one rank, the levels
+  // above the cut are replicated.  cut = first reference level (not the last observed one) with >= 2*world
+  // observed blocks; its blocks, contiguous in device order, are split into `world` runs of equal weight
+  // (weight = sum over the subtree of m*P^2, the factorisation cost).
+  h->blk_owner.assign(nb, -1);
+  h->cut = n_actual;            // nothing sharded unless a cut is found
+  if (h->world > 1) {
+    std::vector<int> cnt(G, 0);
+    for (int i = 0; i < nb; ++i) if (h->blks[i].nobs > 0) cnt[h->blks[i].level]++;
+    for (int g = 0; g + 1 < n_actual; ++g)
+      if (pb->res_is_ref[g] == 1 && cnt[g] >= 2 * h->world) { h->cut = g; break; }
+    if (h->cut < n_actual) {
+      const int cut = h->cut;
+      std::vector<int> root_of(nb, -1);   // device index of the cut-level ancestor (or self)
+      std::vector<double> wsub(nb, 0.0);
+      for (int i = 0; i < nb; ++i) {
+        const Blk &B = h->blks[i];
+        if (B.level < cut) continue;
+        int r = -1;
+        if (B.level == cut) r = i;
+        else for (int t = 0; t < B.nanc; ++t) { const int a = h->anc_idx[B.anc_ptr + t]; if (h->blks[a].level == cut) r = a; }
+        if (r < 0) return fail_create(h, ST_ERR_TOPOLOGY, "block below the cut level without an ancestor on it");
+        root_of[i] = r;
+        wsub[r] += (double)B.m * ((double)B.P * B.P + 1.0);
+      }
+      std::vector<int> roots;
+      double tot = 0;
+      for (int i = 0; i < nb; ++i) if (h->blks[i].level == cut && h->blks[i].nobs > 0) { roots.push_back(i); tot += wsub[i]; }
+      double acc_w = 0;
+      std::vector<int> root_owner(nb, 0);
+      for (size_t k = 0; k < roots.size(); ++k) {
+        int r = (int)std::floor((acc_w + 0.5 * wsub[roots[k]]) / tot * h->world);
+        r = std::min(std::max(r, 0), h->world - 1);
+        if (k > 0) r = std::max(r, root_owner[roots[k - 1]]);   // keep runs contiguous
+        root_owner[roots[k]] = r;
+        acc_w += wsub[roots[k]];
+      }
+      for (int i = 0; i < nb; ++i) if (root_of[i] >= 0) h->blk_owner[i] = root_owner[root_of[i]];
+    }
+  }
+  if (plan_only) {
+    if (owner_out) for (int i = 0; i < nb; ++i) owner_out[h->blks[i].model_id] = h->blk_owner[i];
+    if (cut_out) *cut_out = h->cut;
+    delete h;
+    return ST_OK;
+  }
 
   // ---- level lists (u_by_block_groups) and per-level launch geometry
   hipDeviceProp_t prop;
@@ -1855,6 +1930,49 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
         return fail_create(h, ST_ERR_UNSUPPORTED, "more than 64 direct child groups under one block");
     }
   }
+  // this rank's runs per level, exchange masks, cut-level record region
+  std::vector<unsigned char> rowmask(n, 0), blkmask(nb, 0);
+  for (int g = 0; g < n_actual; ++g) {
+    LevelInfo &L = h->levels[g];
+    L.own_lo = 0; L.own_n = L.count; L.gown_lo = 0; L.gown_n = L.grp_count;
+    if (g >= h->cut) {
+      int lo = L.count, hi = 0;
+      for (int k = 0; k < L.count; ++k)
+        if (h->blk_owner[h->lvl_list[L.first + k]] == h->rank) { lo = std::min(lo, k); hi = std::max(hi, k + 1); }
+      L.own_lo = lo < hi ? lo : 0; L.own_n = lo < hi ? hi - lo : 0;
+      for (int k = L.own_lo; k < L.own_lo + L.own_n; ++k)
+        if (h->blk_owner[h->lvl_list[L.first + k]] != h->rank) return fail_create(h, ST_ERR_TOPOLOGY, "a rank's blocks are not contiguous in a level");
+      if (L.fast) {
+        int glo = L.grp_count, ghi = 0;
+        for (int k = 0; k < L.grp_count; ++k) {
+          const Grp &Gr = h->grps[L.grp_first + k];
+          const bool mine = h->blk_owner[Gr.blk0] == h->rank;
+          for (int b2 = 0; b2 < Gr.nblk; ++b2)
+            if ((h->blk_owner[Gr.blk0 + b2] == h->rank) != mine) return fail_create(h, ST_ERR_TOPOLOGY, "a column group straddles two ranks");
+          if (mine) { glo = std::min(glo, k); ghi = std::max(ghi, k + 1); }
+        }
+        L.gown_lo = glo < ghi ? glo : 0; L.gown_n = glo < ghi ? ghi - glo : 0;
+      }
+    }
+  }
+  for (int i = 0; i < nb; ++i) {
+    const Blk &B = h->blks[i];
+    const bool mine = (h->blk_owner[i] == h->rank) || (h->blk_owner[i] < 0 && h->rank == 0);
+    blkmask[i] = mine ? 1 : 0;
+    if (mine) for (int r2 = 0; r2 < B.m; ++r2) rowmask[B.row0 + r2] = 1;
+    if (B.nobs > 0 && (h->blk_owner[i] < 0 || h->blk_owner[i] == h->rank)) h->own_obs_list.push_back(i);
+  }
+  if (h->cut < n_actual) {
+    const LevelInfo &L = h->levels[h->cut];
+    long long lo = -1, hi = -1;
+    for (int k = 0; k < L.count; ++k) {
+      const Blk &B = h->blks[h->lvl_list[L.first + k]];
+      if (lo < 0) lo = B.acc_off;
+      hi = B.acc_off + B.acc_len;
+      if (h->blk_owner[h->lvl_list[L.first + k]] != h->rank && B.acc_len > 0) h->top_zero.push_back({B.acc_off, (long long)B.acc_len});
+    }
+    h->top_off = std::max(0LL, lo); h->top_len = hi > lo ? hi - lo : 0;
+  }
   for (int i = 0; i < nb; ++i) {
     if (h->blks[i].nobs > 0) h->all_obs_list.push_back(i);
     else {
@@ -1919,7 +2037,10 @@ extern "C" int st_create(const st_problem *pb, const st_options *opt, st_handle 
   { std::vector<Grp> g = h->grps; if (g.empty()) g.push_back(Grp{0, 0, 0, 0, 0}); CCHK(h->d_grps.upload(g)); }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
-  CCHK(h->d_w.alloc(n)); CCHK(h->d_xb.alloc(n)); CCHK(h->d_z.alloc(n)); CCHK(h->d_tmp_n.alloc(n));
+  { std::vector<int> a = h->own_obs_list; if (a.empty()) a.push_back(0); CCHK(h->d_ownobs.upload(a)); }
+  CCHK(h->d_rowmask.upload(rowmask)); CCHK(h->d_blkmask.upload(blkmask));
+  CCHK(h->d_comm.alloc((size_t)2 * nb + 64));
+  CCHK(h->d_w.alloc(n)); CCHK(h->d_xb.alloc(n)); CCHK(h->d_z.alloc(n)); CCHK(h->d_tmp_n.alloc(n + 64));
   CCHK(hipMemset(h->d_w.p, 0, n * sizeof(double)));
   CCHK(hipMemset(h->d_xb.p, 0, n * sizeof(double)));
   CCHK(hipMemset(h->d_z.p, 0, n * sizeof(double)));
@@ -2037,6 +2158,29 @@ extern "C" int st_synchronize(st_handle h) {
   return ST_OK;
 }
 extern "C" void *st_stream(st_handle h) { return h ? (void *)h->stream : nullptr; }
+// run every kernel on the caller's stream (e.g. the stream RCCL collectives are enqueued on): no host synchronisation
+// is then needed between the library's kernels and the exchanges
+extern "C" int st_set_stream(st_handle h, void *stream) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  prof_harvest(h);
+  if (h->stream && !h->ext_stream) (void)hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)stream;
+  h->ext_stream = true;
+  return ST_OK;
+}
+extern "C" int st_shard_info(st_handle h, int32_t *rank, int32_t *world, int32_t *cut_level, int64_t *owned_blocks, int64_t *owned_rows) {
+  if (!h) return ST_ERR_USAGE;
+  if (rank) *rank = h->rank;
+  if (world) *world = h->world;
+  if (cut_level) *cut_level = h->cut;
+  long long ob = 0, orow = 0;
+  for (size_t i = 0; i < h->blks.size(); ++i) if (h->blk_owner[i] == h->rank) { ++ob; orow += h->blks[i].m; }
+  if (owned_blocks) *owned_blocks = ob;
+  if (owned_rows) *owned_rows = orow;
+  return ST_OK;
+}
 
 // CovarianceParams::transform (covariance_functions.cpp:34-75) + vec_to_symmat (:77-92)
 static int make_covpar(st_handle h, const double *theta, int ntheta, CovPar *cp) {
@@ -2088,21 +2232,30 @@ static int reset_err(st_handle h) {
   return ST_OK;
 }
 
-extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik) {
-  if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
-  HCHK(h, hipSetDevice(h->device));
-  CovPar cp;
-  int rc = make_covpar(h, theta, ntheta, &cp);
-  if (rc) return rc;
-  h->theta[slot].assign(theta, theta + ntheta);
-  const int phys = h->slot_map[slot];
-  rc = reset_err(h);
-  if (rc) return rc;
+// sum-with-zeros exchange buffers: every entry is contributed by exactly one rank (replicated blocks by rank 0), so
+// an all-reduce(sum) reproduces the single-GPU arrays bit for bit, for any number of ranks and any reduction order
+__global__ void k_pack_comps(const double *logdet, const double *loglik, const unsigned char *mask, int nb, const int *err, int rank,
+                             int world, double *buf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) {
+    buf[i] = mask[i] ? logdet[i] : 0.0;
+    buf[nb + i] = mask[i] ? loglik[i] : 0.0;
+  }
+  if (i < world) buf[2 * nb + i] = (i == rank && err[0] != INT_MAX) ? (double)err[0] : 0.0;
+}
+__global__ void k_pack_w(const double *w, const unsigned char *mask, long long n, const int *err, int rank, int world, double *buf) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) buf[i] = mask[i] ? w[i] : 0.0;
+  if (i < world) buf[n + i] = (i == rank && err[0] != INT_MAX) ? (double)err[0] : 0.0;
+}
+
+static int factor_launch(st_handle h, int phys, const CovPar &cp) {
   for (int g = 0; g < h->n_actual_groups; ++g) {
     const LevelInfo &L = h->levels[g];
+    if ((L.fast ? L.gown_n : L.own_n) == 0) continue;
     FactorArgs A;
     std::memset(&A, 0, sizeof(A));
-    A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_lvl.p + L.first; A.nlist = L.count;
+    A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_lvl.p + L.first + L.own_lo; A.nlist = L.own_n;
     A.cx = h->d_cx.p; A.cy = h->d_cy.p; A.mv = h->d_mv.p; A.w_in = h->d_w.p; A.w_out = nullptr; A.z = nullptr;
     A.panels = h->d_panels[phys].p; A.logdet_c = h->d_logdet[phys].p; A.loglik_c = h->d_loglik[phys].p;
     A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
@@ -2111,22 +2264,78 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
       if (L.fast) {
         FastArgs F;
         std::memset(&F, 0, sizeof(F));
-        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first; F.ngrp = L.grp_count;
+        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
         F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p;
         F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
-        hipLaunchKernelGGL(k_factor_mfma, dim3(L.grp_count), dim3(NT), L.lds_fast, h->stream, F, cp);
+        hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, h->stream, F, cp);
       } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
       else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
     }
     HCHK(h, hipGetLastError());
   }
+  return ST_OK;
+}
+
+extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int ntheta) {
+  if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  CovPar cp;
+  int rc = make_covpar(h, theta, ntheta, &cp);
+  if (rc) return rc;
+  h->theta[slot].assign(theta, theta + ntheta);
+  rc = reset_err(h);
+  if (rc) return rc;
+  return factor_launch(h, h->slot_map[slot], cp);
+}
+
+extern "C" int st_mg_pack_comps(st_handle h, int slot, void **dev_ptr, int64_t *len) {
+  if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  const int phys = h->slot_map[slot], nb = (int)h->n_blocks;
+  {
+    ProfScope ps(h, 3);
+    hipLaunchKernelGGL(k_pack_comps, dim3((std::max(nb, h->world) + NT - 1) / NT), dim3(NT), 0, h->stream, h->d_logdet[phys].p,
+                       h->d_loglik[phys].p, h->d_blkmask.p, nb, h->d_err.p, h->rank, h->world, h->d_comm.p);
+  }
+  HCHK(h, hipGetLastError());
+  if (dev_ptr) *dev_ptr = h->d_comm.p;
+  if (len) *len = 2 * (int64_t)nb + h->world;
+  return ST_OK;
+}
+
+// after the exchange of the packed components: deterministic sum + failure code agreed by all ranks
+extern "C" int st_mg_finish(st_handle h, double *loglik) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  const int nb = (int)h->n_blocks;
+  {
+    ProfScope ps(h, 3);
+    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(1024), 0, h->stream, h->d_comm.p, h->d_comm.p + nb, nb, h->d_scalars.p);
+  }
+  HCHK(h, hipGetLastError());
+  double s2[2], errw[64];
+  HCHK(h, hipMemcpyAsync(s2, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipMemcpyAsync(errw, h->d_comm.p + 2 * (size_t)nb, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  int best = INT_MAX;
+  for (int r = 0; r < h->world; ++r) if (errw[r] > 0.5) best = std::min(best, (int)errw[r]);
+  if (best != INT_MAX) return best & 15;
+  if (loglik) *loglik = s2[0] + s2[1];   // loglik_w = logdetCi + sum(loglik_w_comps)  (:987-988, :815-816)
+  return ST_OK;
+}
+
+extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik) {
+  if (!h) return ST_ERR_USAGE;
+  if (h->world > 1) { h->err = "world > 1: use st_factor_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+  int rc = st_factor_local(h, slot, theta, ntheta);
+  if (rc) return rc;
   int code = 0;
   rc = read_err(h, &code);
   if (rc) return rc;
   if (code) return code;  // the reference's `return false` (:971-982); deeper levels hold unspecified values (Q5)
   double ll = 0.0;
-  rc = reduce_loglik(h, phys, &ll);
+  rc = reduce_loglik(h, h->slot_map[slot], &ll);
   if (rc) return rc;
   if (loglik) *loglik = ll;
   return ST_OK;
@@ -2144,20 +2353,14 @@ static int gen_or_upload_z(st_handle h, const double *z, uint64_t seed, uint32_t
   return ST_OK;
 }
 
-extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
-  if (!h) return ST_ERR_USAGE;
-  HCHK(h, hipSetDevice(h->device));
-  int rc = gen_or_upload_z(h, z, seed, iter, 0u, h->d_z.p);
-  if (rc) return rc;
-  h->z_valid = true;
-  rc = reset_err(h);
-  if (rc) return rc;
+static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 ... g_lo
   const int phys = h->slot_map[0];
-  for (int g = h->n_actual_groups - 1; g >= 0; --g) {
+  for (int g = g_hi - 1; g >= g_lo; --g) {
     const LevelInfo &L = h->levels[g];
+    if ((L.fast ? L.gown_n : L.own_n) == 0) continue;
     SampleArgs A;
     std::memset(&A, 0, sizeof(A));
-    A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.dch_idx = h->d_dch.p; A.list = h->d_lvl.p + L.first; A.nlist = L.count;
+    A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.dch_idx = h->d_dch.p; A.list = h->d_lvl.p + L.first + L.own_lo; A.nlist = L.own_n;
     A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.y = h->d_y.p; A.xb = h->d_xb.p; A.z = h->d_z.p; A.mv = h->d_mv.p;
     A.obs = h->d_obs.p; A.acc = h->d_acc.p; A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxLd = L.maxLd;
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
@@ -2166,27 +2369,86 @@ extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t
       if (L.fast) {
         SampleFastArgs F;
         std::memset(&F, 0, sizeof(F));
-        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first; F.ngrp = L.grp_count;
+        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.maxP = L.maxP;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
-        hipLaunchKernelGGL(k_sample_mfma, dim3(L.grp_count), dim3(NT), L.lds_sfast, h->stream, F);
+        hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
       } else if (L.big_sample) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
-        hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.count, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
+        hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
       } else {
-        hipLaunchKernelGGL((k_sample<false>), dim3(L.count), dim3(NT), L.lds_sample, h->stream, A);
+        hipLaunchKernelGGL((k_sample<false>), dim3(L.own_n), dim3(NT), L.lds_sample, h->stream, A);
       }
     }
     HCHK(h, hipGetLastError());
   }
+  return ST_OK;
+}
+
+// levels below the cut (this rank's subtrees); then the cut level's message records of the other ranks are zeroed so
+// that an all-reduce(sum) over st_mg_top_region() completes them
+extern "C" int st_sample_w_local(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  int rc = gen_or_upload_z(h, z, seed, iter, 0u, h->d_z.p);
+  if (rc) return rc;
+  h->z_valid = true;
+  rc = reset_err(h);
+  if (rc) return rc;
+  rc = sample_launch(h, h->n_actual_groups, std::min(h->cut, h->n_actual_groups));
+  if (rc) return rc;
+  for (auto &zr : h->top_zero) HCHK(h, hipMemsetAsync(h->d_acc.p + zr.first, 0, (size_t)zr.second * sizeof(double), h->stream));
+  return ST_OK;
+}
+extern "C" int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len) {
+  if (!h) return ST_ERR_USAGE;
+  if (dev_ptr) *dev_ptr = h->d_acc.p + h->top_off;
+  if (len) *len = h->top_len;
+  return ST_OK;
+}
+extern "C" int st_sample_w_top(st_handle h) {   // the replicated levels above the cut
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  return sample_launch(h, std::min(h->cut, h->n_actual_groups), 0);
+}
+extern "C" int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  const long long nn = std::max<long long>(h->n_all, h->world);
+  hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((nn + NT - 1) / NT)), dim3(NT), 0, h->stream, h->d_w.p, h->d_rowmask.p, h->n_all, h->d_err.p,
+                     h->rank, h->world, h->d_tmp_n.p);
+  HCHK(h, hipGetLastError());
+  if (dev_ptr) *dev_ptr = h->d_tmp_n.p;
+  if (len) *len = h->n_all + h->world;
+  return ST_OK;
+}
+extern "C" int st_mg_unpack_w(st_handle h) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  double errw[64];
+  HCHK(h, hipMemcpyAsync(h->d_w.p, h->d_tmp_n.p, (size_t)h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  HCHK(h, hipMemcpyAsync(errw, h->d_tmp_n.p + h->n_all, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  int best = INT_MAX;
+  for (int r = 0; r < h->world; ++r) if (errw[r] > 0.5) best = std::min(best, (int)errw[r]);
+  return best == INT_MAX ? ST_OK : (best & 15);
+}
+
+extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
+  if (!h) return ST_ERR_USAGE;
+  if (h->world > 1) { h->err = "world > 1: use st_sample_w_local / st_mg_top_region / st_sample_w_top / st_mg_pack_w / st_mg_unpack_w"; return ST_ERR_USAGE; }
+  int rc = st_sample_w_local(h, z, seed, iter);
+  if (rc) return rc;
+  rc = st_sample_w_top(h);
+  if (rc) return rc;
   int code = 0;
   rc = read_err(h, &code);
   if (rc) return rc;
   return code;  // 10 / 11: the reference stops with "Error at gibbs_sample_w" (:1215-1217)
 }
 
-extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {
+extern "C" int st_loglik_local(st_handle h, int slot) {
   if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
   const int phys = h->slot_map[slot];
@@ -2194,15 +2456,23 @@ extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {
   for (auto &L : h->levels) { maxP = std::max(maxP, L.maxP); maxM = std::max(maxM, L.maxM); }
   const size_t lds = lds_loglik_bytes(maxP, maxM);
   LoglikArgs A;
-  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_allobs.p; A.nlist = (int)h->all_obs_list.size();
+  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_ownobs.p; A.nlist = (int)h->own_obs_list.size();
   A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.loglik_c = h->d_loglik[phys].p; A.maxP = maxP; A.maxM = maxM;
-  {
+  if (A.nlist > 0) {
     ProfScope ps(h, 2);
     hipLaunchKernelGGL(k_loglik, dim3(A.nlist), dim3(NT), lds, h->stream, A);
   }
   HCHK(h, hipGetLastError());
+  HCHK(h, reset_err(h) == ST_OK ? hipSuccess : hipErrorUnknown);
+  return ST_OK;
+}
+extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {
+  if (!h) return ST_ERR_USAGE;
+  if (h->world > 1) { h->err = "world > 1: use st_loglik_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+  int rc = st_loglik_local(h, slot);
+  if (rc) return rc;
   double ll = 0.0;
-  int rc = reduce_loglik(h, phys, &ll);
+  rc = reduce_loglik(h, h->slot_map[slot], &ll);
   if (rc) return rc;
   if (loglik) *loglik = ll;
   return ST_OK;

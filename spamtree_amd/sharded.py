@@ -1,0 +1,122 @@
+"""Multi-GPU: one process per GPU, all sharing ONE problem.
+
+`ShardedSpamTreeMV` is `SpamTreeMV` with the three sharded phases composed from the library's local steps and an
+all-reduce(sum) through `torch.distributed` in between (backend "nccl" = RCCL over xGMI on the stream the library
+launches on; backend "gloo" stages through host memory and is what the single-GPU / CPU tests use).  Each exchanged
+entry is contributed by exactly one rank and is zero elsewhere, so results are bit-identical to the single-GPU run
+for any number of ranks.  Ownership (whole subtrees below a cut level; replicated top) is decided inside the
+library (`st_shard_plan`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .model import SpamTreeMV, SpamTreeError, _dp, _f64
+
+
+class _DevArray:
+    """Zero-copy view of a library-owned device buffer for torch (`__cuda_array_interface__`)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def shard_plan(pb_struct, world):
+    """owner[u] (rank, or -1 = replicated) and the cut level, from the library's pure-host planner."""
+    lib = _lib.load()
+    nb = int(pb_struct.n_blocks)
+    owner = np.zeros(nb, dtype=np.int64)
+    cut = C.c_int32()
+    rc = lib.st_shard_plan(C.byref(pb_struct), int(world), owner.ctypes.data_as(_lib.c_ip), C.byref(cut))
+    if rc != 0:
+        raise SpamTreeError(f"st_shard_plan failed ({rc}): {lib.st_last_error(None).decode()}")
+    return owner, cut.value
+
+
+class ShardedSpamTreeMV(SpamTreeMV):
+    def __init__(self, *args, dist=None, force_protocol=False, **kw):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.force_protocol = bool(force_protocol)   # run the local/exchange/finish steps even with one rank (tests)
+        rank = dist.get_rank() if dist is not None else 0
+        world = dist.get_world_size() if dist is not None else 1
+        self.backend = dist.get_backend() if dist is not None else None
+        super().__init__(*args, rank=rank, world=world, **kw)
+        self.device_index = kw.get("device", 0)
+        if self.backend == "nccl":
+            # kernels and collectives share torch's current stream: no host synchronisation between them
+            self._check(self.lib.st_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    # ---- one exchange: all-reduce(sum) of a library-owned device buffer
+    def _allreduce(self, ptr, n):
+        if self.dist is None or n == 0 or (self.world == 1 and not self.force_protocol):
+            return
+        torch = self.torch
+        if self.backend == "nccl":
+            t = torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", self.device_index))
+            self.dist.all_reduce(t)
+        else:
+            self._check(self.lib.st_synchronize(self.h))
+            t = torch.as_tensor(_DevArray(ptr, n), device=torch.device("cuda", self.device_index))
+            host = t.cpu()
+            self.dist.all_reduce(host)
+            t.copy_(host)
+            torch.cuda.synchronize()
+
+    def _exchange_comps(self, slot):
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.st_mg_pack_comps(self.h, slot, C.byref(ptr), C.byref(n)))
+        self._allreduce(ptr.value, n.value)
+        ll = C.c_double(0.0)
+        rc = self._check(self.lib.st_mg_finish(self.h, C.byref(ll)))
+        return rc, ll.value
+
+    def get_loglik_comps_w(self, slot) -> bool:
+        if self.world == 1 and not self.force_protocol:
+            return super().get_loglik_comps_w(slot)
+        th = _f64(self.theta[slot])
+        self._check(self.lib.st_factor_local(self.h, slot, _dp(th), th.size))
+        rc, ll = self._exchange_comps(slot)
+        self.last_errtype = rc if rc > 0 else -1
+        if rc > 0:
+            return False
+        self.loglik_w[slot] = ll
+        return True
+
+    def get_loglik_w(self, slot):
+        if self.world == 1 and not self.force_protocol:
+            return super().get_loglik_w(slot)
+        self._check(self.lib.st_loglik_local(self.h, slot))
+        _, ll = self._exchange_comps(slot)
+        self.loglik_w[slot] = ll
+        return ll
+
+    def deal_with_w(self, z=None, seed=0, it=0):
+        if self.world == 1 and not self.force_protocol:
+            return super().deal_with_w(z, seed, it)
+        if z is not None:
+            z = _f64(z)
+            self._check(self.lib.st_sample_w_local(self.h, _dp(z), 0, 0))
+        else:
+            self._check(self.lib.st_sample_w_local(self.h, None, int(seed), int(it)))
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.st_mg_top_region(self.h, C.byref(ptr), C.byref(n)))
+        self._allreduce(ptr.value, n.value)
+        self._check(self.lib.st_sample_w_top(self.h))
+        self._check(self.lib.st_mg_pack_w(self.h, C.byref(ptr), C.byref(n)))
+        self._allreduce(ptr.value, n.value)
+        rc = self._check(self.lib.st_mg_unpack_w(self.h))
+        if rc > 0:
+            raise SpamTreeError("Error at gibbs_sample_w")
+
+    gibbs_sample_w = deal_with_w
+
+    def shard_info(self):
+        r, w, c = C.c_int32(), C.c_int32(), C.c_int32()
+        ob, orow = C.c_int64(), C.c_int64()
+        self._check(self.lib.st_shard_info(self.h, C.byref(r), C.byref(w), C.byref(c), C.byref(ob), C.byref(orow)))
+        return dict(rank=r.value, world=w.value, cut_level=c.value, owned_blocks=ob.value, owned_rows=orow.value)

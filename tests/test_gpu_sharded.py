@@ -1,0 +1,35 @@
+"""GPU: 2 and 3 processes share ONE problem on device 0 (gloo exchange); every result must equal the single-process
+run bit for bit (ownership by subtree, exchanges are sums with zeros)."""
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("side,q", [(120, 1), (48, 3)])
+def test_sharded_equals_single_process_bitwise(side, q, tmp_path):
+    import torch.multiprocessing as mp
+    from tests._sharded_worker import gpu_worker
+    steps = 2
+    for world in (1, 2, 3):
+        mp.spawn(gpu_worker, args=(world, free_port(), side, q, str(tmp_path), steps), nprocs=world, join=True)
+    ref = np.load(tmp_path / "res_1_0.npz")
+    for world in (2, 3):
+        rows = 0
+        for rank in range(world):
+            r = np.load(tmp_path / f"res_{world}_{rank}.npz")
+            for k in ["ll_A", "ll_A2", "err", "ll_C0", "ll_C1"]:
+                assert float(r[k]) == float(ref[k]), (world, rank, k)
+            assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["xty"], ref["xty"]) and np.array_equal(r["ssq"], ref["ssq"])
+            rows += int(r["owned_rows"])
+        assert 0 < rows <= ref["w"].size
