@@ -73,7 +73,6 @@ def main():
     ap.add_argument("--side", type=int, default=1000, help="grid side; n = side^2 (1000 -> config #3, 316 -> #2)")
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-protocol", action="store_true", help="use the multi-GPU local/exchange/finish steps with 1 rank")
     ap.add_argument("--cpu-side", type=int, default=224, help="grid side of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
@@ -82,36 +81,39 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
-    if world > 1 or "--force-protocol" in sys.argv:
+    if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
 
-    from spamtree_amd.mcmc import Chain
-    from spamtree_amd.sharded import ShardedSpamTreeMV
+    from spamtree_amd import fit
     from spamtree_amd.synthetic import make_workload
 
     t_setup = time.time()
     wl = make_workload(args.side, q=args.q)
-    # one problem shared by all ranks: subtrees below a cut level are owned by one GPU, the top is replicated,
-    # exchanges are RCCL all-reduces on the library's stream (spamtree_amd/sharded.py)
-    model = ShardedSpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
-                              wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"],
-                              wl["block_groups"], wl["indexing"], np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"],
-                              1.0 / 0.1, device=local_rank, dist=dist, force_protocol=args.force_protocol)
+    # N > 1: one problem shared by all ranks -- subtrees below a cut level are owned by one GPU, the top is replicated,
+    # exchanges are RCCL all-reduces issued by the library on its own stream (include/spamtree_hip.h, multi-GPU section)
+    uid = None
+    if world > 1:
+        box = [fit.make_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid = box[0]
     k = wl["theta"].size
-    chain = Chain(model, wl["bounds"], 0.01 * np.eye(k), seed=2021, adapting=True)
+    # the C++ host driver (spamtree_amd/csrc/spamtree_fit.cpp) steps the chain: w sweep, log-density, RAM-adaptive MH with a
+    # full re-factorisation of the proposal slot, tausq and beta draws
+    chain = fit.Chain(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
+                      wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
+                      wl["indexing"], wl["bounds"], wl["theta"], np.zeros(wl["p"]), 0.1, 0.01 * np.eye(k), seed=2021,
+                      adapting=True, device=local_rank, rank=rank, world=world, unique_id=uid)
+    model = chain
+    n_blocks = int(np.asarray(wl["block_names"]).size)
     t_setup = time.time() - t_setup
     alg = model.algorithmic_bytes()
 
     model.profile(True)
-    for _ in range(args.warmup):
-        chain.step()
+    chain.step(args.warmup)
     model.profile_get()
     model.profile_levels()
 
@@ -124,8 +126,7 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        chain.step()
+    chain.step(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -151,10 +152,10 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"config #3: n={wl['n']} ({args.side}^2 grid) q={args.q} univariate exponential "
-                               f"covariance, default tree (cell_size=25, K=(2,2)), {model.n_blocks} blocks, "
+                               f"covariance, default tree (cell_size=25, K=(2,2)), {n_blocks} blocks, "
                                "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH"
                                + (f"; sharded over {world} GPUs by subtree, RCCL all-reduce exchanges" if world > 1 else ""),
-                   "n": int(wl["n"]), "q": args.q, "blocks": int(model.n_blocks), "levels": int(n_levels),
+                   "n": int(wl["n"]), "q": args.q, "blocks": int(n_blocks), "levels": int(n_levels),
                    "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
                        alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_factor (phase A: covariance build + chain solve + Cholesky)",

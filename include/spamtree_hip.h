@@ -147,6 +147,10 @@ int st_set_stream(st_handle h, void *stream);              /* launch on the call
  *   phase C : st_loglik_local -> st_mg_pack_comps -> all-reduce(buf) -> st_mg_finish
  *   phase B : st_sample_w_local -> all-reduce(st_mg_top_region) -> st_sample_w_top
  *             -> st_mg_pack_w -> all-reduce(buf) -> st_mg_unpack_w                           (code 0/10/11) */
+/* native exchange: rank 0 creates a 128-byte RCCL unique id (returns its size), every rank passes it to st_comm_init;
+ * afterwards the single-call forms run the steps above with ncclAllReduce on the library's stream */
+int st_comm_unique_id(void *out, int32_t cap);
+int st_comm_init(st_handle h, const void *unique_id);
 int st_shard_plan(const st_problem *pb, int32_t world, int64_t *owner /* n_blocks */, int32_t *cut_level);
 int st_shard_info(st_handle h, int32_t *rank, int32_t *world, int32_t *cut_level, int64_t *owned_blocks, int64_t *owned_rows);
 int st_factor_local(st_handle h, int slot, const double *theta, int ntheta);

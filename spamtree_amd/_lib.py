@@ -63,7 +63,30 @@ SIGNATURES = {
     "st_sample_w_top": (C.c_int, [H]),
     "st_mg_pack_w": (C.c_int, [H, C.POINTER(C.c_void_p), c_ip]),
     "st_mg_unpack_w": (C.c_int, [H]),
+    "st_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int32]),
+    "st_comm_init": (C.c_int, [H, C.c_void_p]),
 }
+
+
+class StmFlags(C.Structure):
+    _fields_ = [("adapting", C.c_int32), ("sample_beta", C.c_int32), ("sample_tausq", C.c_int32),
+                ("sample_theta", C.c_int32), ("sample_w", C.c_int32), ("sample_predicts", C.c_int32)]
+
+
+# include/spamtree_fit.h (C++ host driver)
+SIGNATURES.update({
+    "stm_create": (C.c_int, [C.POINTER(StProblem), C.POINTER(StOptions), c_dp, c_dp, c_dp, C.c_int, c_dp, C.c_double,
+                             C.c_uint64, C.POINTER(StmFlags), C.POINTER(H)]),
+    "stm_init": (C.c_int, [H]),
+    "stm_destroy": (C.c_int, [H]),
+    "stm_last_error": (C.c_char_p, [H]),
+    "stm_handle": (C.c_void_p, [H]),
+    "stm_step": (C.c_int, [H, C.c_int]),
+    "stm_state": (C.c_int, [H, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp]),
+    "spamtree_mv_mcmc_c": (C.c_int, [C.POINTER(StProblem), C.POINTER(StOptions), c_dp, c_dp, C.c_int, c_dp, C.c_double,
+                                     c_dp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(StmFlags), c_dp, c_dp,
+                                     c_dp, c_dp, c_dp, c_dp, c_dp]),
+})
 
 _lib = None
 

@@ -19,12 +19,12 @@ def _newer(target, sources):
 def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".cpp"))]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + \
-        [os.path.join(ROOT, "include", "spamtree_hip.h")]
+        [os.path.join(ROOT, "include", "spamtree_hip.h"), os.path.join(ROOT, "include", "spamtree_fit.h")]
     if not force and not _newer(LIB, deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
-           "-I", CSRC, "-o", LIB] + [s for s in srcs]
+           "-I", CSRC, "-o", LIB] + [s for s in srcs] + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "spamtree_hip.h"
+#include <rccl/rccl.h>
 
 #define NT 256
 #define MAXJ ST_MAX_ANCESTORS
@@ -1399,12 +1400,19 @@ __global__ __launch_bounds__(NT) void k_stats(const double *X, const double *y, 
     if (threadIdx.x == 0) partial[(size_t)blockIdx.x * nq + k] = s;
   }
 }
-__global__ void k_stats_final(const double *partial, int nwg, int nq, double *out) {
-  const int k = threadIdx.x;
-  if (k >= nq) return;
+// one workgroup per statistic: fixed-shape tree over the STATS_WG partial sums (deterministic)
+__global__ __launch_bounds__(NT) void k_stats_final(const double *partial, int nwg, int nq, double *out) {
+  __shared__ double sm[NT];
+  const int k = blockIdx.x;
   double s = 0.0;
-  for (int g = 0; g < nwg; ++g) s += partial[(size_t)g * nq + k];
-  out[k] = s;
+  for (int g = threadIdx.x; g < nwg; g += NT) s += partial[(size_t)g * nq + k];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[k] = sm[0];
 }
 
 __global__ void k_yhat(const double *xb, const double *w, const double *noise, const int *mv, long long n, const double *tsq_inv_q,
@@ -1479,6 +1487,7 @@ struct st_handle_s {
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
   std::vector<std::pair<long long, long long>> top_zero;   // sub-ranges of it owned by other ranks
   bool ext_stream = false;
+  ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
   std::vector<LevelInfo> levels;
   LevelInfo pred_info;
   std::vector<double> xtx;
@@ -1592,6 +1601,7 @@ extern "C" int st_destroy(st_handle h) {
   h->d_ownobs.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
+  if (h->comm) (void)ncclCommDestroy(h->comm);
   if (h->stream && !h->ext_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ST_OK;
@@ -2325,9 +2335,46 @@ extern "C" int st_mg_finish(st_handle h, double *loglik) {
   return ST_OK;
 }
 
+#define NCHK(h, call)                                                                                        \
+  do {                                                                                                        \
+    ncclResult_t r_ = (call);                                                                                 \
+    if (r_ != ncclSuccess) { (h)->err = std::string(#call) + ": " + ncclGetErrorString(r_); return ST_ERR_HIP; } \
+  } while (0)
+
+// pack -> RCCL all-reduce(sum) on the launch stream -> deterministic finish (native path of the multi-GPU protocol)
+static int exchange_comps_and_finish(st_handle h, int slot, double *loglik) {
+  void *ptr = nullptr;
+  int64_t len = 0;
+  int rc = st_mg_pack_comps(h, slot, &ptr, &len);
+  if (rc) return rc;
+  NCHK(h, ncclAllReduce(ptr, ptr, (size_t)len, ncclDouble, ncclSum, h->comm, h->stream));
+  return st_mg_finish(h, loglik);
+}
+
+extern "C" int st_comm_unique_id(void *out, int32_t cap) {
+  if (!out || cap < (int32_t)sizeof(ncclUniqueId)) return ST_ERR_USAGE;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return ST_ERR_HIP;
+  std::memcpy(out, &id, sizeof(id));
+  return (int)sizeof(id);
+}
+extern "C" int st_comm_init(st_handle h, const void *unique_id) {
+  if (!h || !unique_id) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  NCHK(h, ncclCommInitRank(&h->comm, h->world, id, h->rank));
+  return ST_OK;
+}
+
 extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik) {
   if (!h) return ST_ERR_USAGE;
-  if (h->world > 1) { h->err = "world > 1: use st_factor_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+  if (h->world > 1) {
+    if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_factor_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+    int rc = st_factor_local(h, slot, theta, ntheta);
+    if (rc) return rc;
+    return exchange_comps_and_finish(h, slot, loglik);
+  }
   int rc = st_factor_local(h, slot, theta, ntheta);
   if (rc) return rc;
   int code = 0;
@@ -2437,7 +2484,20 @@ extern "C" int st_mg_unpack_w(st_handle h) {
 
 extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
   if (!h) return ST_ERR_USAGE;
-  if (h->world > 1) { h->err = "world > 1: use st_sample_w_local / st_mg_top_region / st_sample_w_top / st_mg_pack_w / st_mg_unpack_w"; return ST_ERR_USAGE; }
+  if (h->world > 1) {
+    if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_sample_w_local / st_mg_top_region / st_sample_w_top / st_mg_pack_w / st_mg_unpack_w"; return ST_ERR_USAGE; }
+    int rc = st_sample_w_local(h, z, seed, iter);
+    if (rc) return rc;
+    if (h->top_len > 0) NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
+    rc = st_sample_w_top(h);
+    if (rc) return rc;
+    void *ptr = nullptr;
+    int64_t len = 0;
+    rc = st_mg_pack_w(h, &ptr, &len);
+    if (rc) return rc;
+    NCHK(h, ncclAllReduce(ptr, ptr, (size_t)len, ncclDouble, ncclSum, h->comm, h->stream));
+    return st_mg_unpack_w(h);
+  }
   int rc = st_sample_w_local(h, z, seed, iter);
   if (rc) return rc;
   rc = st_sample_w_top(h);
@@ -2468,7 +2528,12 @@ extern "C" int st_loglik_local(st_handle h, int slot) {
 }
 extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {
   if (!h) return ST_ERR_USAGE;
-  if (h->world > 1) { h->err = "world > 1: use st_loglik_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+  if (h->world > 1) {
+    if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_loglik_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+    int rc = st_loglik_local(h, slot);
+    if (rc) return rc;
+    return exchange_comps_and_finish(h, slot, loglik);
+  }
   int rc = st_loglik_local(h, slot);
   if (rc) return rc;
   double ll = 0.0;
@@ -2511,7 +2576,7 @@ static int run_stats(st_handle h) {
     ProfScope ps(h, 4);
     hipLaunchKernelGGL(k_stats, dim3(STATS_WG), dim3(NT), 0, h->stream, h->d_X.p, h->d_y.p, h->d_w.p, h->d_xb.p, h->d_mv.p, h->d_obs.p,
                        h->d_partner.p, h->n_all, h->p, h->q, h->d_partial.p);
-    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(64), 0, h->stream, h->d_partial.p, STATS_WG, nq, h->d_stats.p);
+    hipLaunchKernelGGL(k_stats_final, dim3(nq), dim3(NT), 0, h->stream, h->d_partial.p, STATS_WG, nq, h->d_stats.p);
   }
   HCHK(h, hipGetLastError());
   return ST_OK;

@@ -9,9 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "spamtree_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(st_[a-z_0-9]+)\s*\(", txt)))
+    syms = set()
+    for hdr in ("spamtree_hip.h", "spamtree_fit.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        syms |= set(re.findall(r"\b((?:st|stm)_[a-z_0-9]+|spamtree_mv_mcmc_c)\s*\(", txt))
+    return sorted(syms)
 
 
 def test_header_declares_the_boundary():

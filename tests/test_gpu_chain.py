@@ -1,0 +1,52 @@
+"""GPU: whole chains.  The C++ host driver (spamtree_amd/csrc/spamtree_fit.cpp through spamtree_amd/fit.py) and the
+Python host driver (spamtree_amd/mcmc.py) against the oracle's restatement of spamtree_mv_mcmc with the same Philox
+streams: theta / beta / tausq traces, saved w and yhat."""
+import numpy as np
+import pytest
+
+from tests.util import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def args_of(pb, k):
+    return (pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"], pb["res_is_ref"],
+            pb["parents"], pb["children"], False, pb["block_names"], pb["block_groups"], pb["indexing"], pb["bounds"],
+            np.zeros((pb["n"], 1)), pb["theta"], np.zeros(pb["p"]), 0.1, 0.01 * np.eye(k))
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max()))
+
+
+@pytest.mark.parametrize("case", [dict(side=25, q=1, seed=11, missing=0.1), dict(side=12, q=2, seed=12)])
+def test_cpp_and_python_drivers_match_oracle_chain(case):
+    from oracle import spamtree_oracle as so
+    from spamtree_amd import fit, mcmc
+    pb = make_problem(**case)
+    k = pb["theta"].size
+    kw = dict(mcmc_keep=4, mcmc_burn=58, mcmc_thin=2, adapting=True, seed=99, main_verbose=False)   # crosses g0 = 50
+    ref = so.spamtree_mv_mcmc(*args_of(pb, k), **kw)
+    for drv in (fit.spamtree_mv_mcmc, mcmc.spamtree_mv_mcmc):
+        got = drv(*args_of(pb, k), **kw)
+        assert "None" not in got
+        assert relerr(got["theta_mcmc"], ref["theta_mcmc"]) < 1e-8
+        assert relerr(got["tausq_mcmc"], ref["tausq_mcmc"]) < 1e-8
+        assert relerr(got["beta_mcmc"], ref["beta_mcmc"]) < 1e-8
+        assert relerr(got["paramsd"], ref["paramsd"]) < 1e-7
+        for i in range(4):
+            assert relerr(np.asarray(got["w_mcmc"][i]).reshape(-1), ref["w_mcmc"][i]) < 1e-8
+            assert relerr(np.asarray(got["yhat_mcmc"][i]).reshape(-1), ref["yhat_mcmc"][i]) < 1e-8
+
+
+def test_cpp_chain_steps_and_reports_state():
+    from spamtree_amd import fit
+    pb = make_problem(side=25, q=1, seed=3)
+    ch = fit.Chain(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"], pb["res_is_ref"],
+                   pb["parents"], pb["children"], False, pb["block_names"], pb["block_groups"], pb["indexing"],
+                   pb["bounds"], pb["theta"], np.zeros(pb["p"]), 0.1, 0.01 * np.eye(4), seed=5)
+    ch.step(20)
+    st = ch.state()
+    assert st["iteration"] == 20 and np.all(np.isfinite(st["theta"])) and np.all(st["tausq_inv"] > 0)
+    assert np.isfinite(st["loglik"]) and np.all(np.isfinite(ch.get_w()))
+    ch.close()
