@@ -385,40 +385,42 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
+// shared core: in-register Cholesky (lane i owns row i) followed by the columns of L^{-1} (lane j owns column j).
+// dinv = 1 / L[lane][lane].  Divisions and square roots are replaced by one rsqrt per pivot.
+#define WAVE_CHOL_CORE(SRC, m, lane, a, x, dinv, bad)                                                         \
+  {                                                                                                           \
+    const int li_ = min(lane, (m) - 1);                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 32; ++j) {                                                          \
+      const double v_ = (SRC)[li_ * (m) + min(j, (m) - 1)];                                                   \
+      a[j] = (lane < (m) && j <= lane) ? v_ : ((j == lane) ? 1.0 : 0.0);                                      \
+    }                                                                                                         \
+    _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                          \
+      if (k < (m)) {                                                                                          \
+        const double dkk_ = readlane_f64(a[k], k);                                                            \
+        bad = bad || !(dkk_ > 0.0);                                                                           \
+        const double rs_ = rsqrt(dkk_);                                                                       \
+        a[k] = (lane == k) ? dkk_ * rs_ : a[k] * rs_;                                                         \
+        dinv = (lane == k) ? rs_ : dinv;                                                                      \
+        _Pragma("unroll") for (int j = k + 1; j < 32; ++j) {                                                  \
+          if (j < (m)) a[j] -= a[k] * readlane_f64(a[k], j);                                                  \
+        }                                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 32; ++i) {                                                          \
+      double sacc_ = (i == lane) ? 1.0 : 0.0;                                                                 \
+      if (i < (m)) {                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < i; ++k) sacc_ -= readlane_f64(a[k], i) * x[k];                  \
+        sacc_ *= readlane_f64(dinv, i);                                                                       \
+      }                                                                                                       \
+      x[i] = sacc_;                                                                                           \
+    }                                                                                                         \
+  }
+
 __device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fail, int lane) {
-  double a[32];
-  const int li = min(lane, m - 1);
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const double v = R[li * m + min(j, m - 1)];
-    a[j] = (lane < m && j <= lane) ? v : ((j == lane) ? 1.0 : 0.0);
-  }
+  double a[32], x[32], dinv = 1.0;
   bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    if (k < m) {
-      const double dkk = readlane_f64(a[k], k);
-      bad = bad || !(dkk > 0.0);
-      const double piv = sqrt(dkk), inv = 1.0 / piv;
-      a[k] = (lane == k) ? piv : a[k] * inv;
-#pragma unroll
-      for (int j = k + 1; j < 32; ++j) {
-        if (j < m) a[j] -= a[k] * readlane_f64(a[k], j);
-      }
-    }
-  }
+  WAVE_CHOL_CORE(R, m, lane, a, x, dinv, bad)
   if (bad && lane == 0) *fail = 1;
-  double x[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    double sacc = (i == lane) ? 1.0 : 0.0;
-    if (i < m) {
-#pragma unroll
-      for (int k = 0; k < i; ++k) sacc -= readlane_f64(a[k], i) * x[k];
-      sacc /= readlane_f64(a[i], i);
-    }
-    x[i] = sacc;
-  }
   if (lane < m) {
 #pragma unroll
     for (int i = 0; i < 32; ++i)
@@ -426,53 +428,29 @@ __device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fa
   }
 }
 
-
 // Cholesky of S (m x m, m <= 32, LDS row-major, lower triangle valid) by one wave in registers, then
-// w = L^{-T} (L^{-1} b + z): the block-Gibbs draw of spamtree_model.cpp:1054, 1086 without forming the inverse.
+// w = L^{-T} (L^{-1} b + z): the block-Gibbs draw of spamtree_model.cpp:1054, 1086.  The forward solve is column
+// oriented (broadcast of the solved entry); the transposed solve uses the columns of L^{-1}, so no cross-lane
+// reduction is needed: w_j = sum_i Li[i][j] u_i.
 __device__ void wave_chol_solve_32(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
-  double a[32];
-  const int li = min(lane, m - 1);
-#pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const double v = S[li * m + min(j, m - 1)];
-    a[j] = (lane < m && j <= lane) ? v : ((j == lane) ? 1.0 : 0.0);
-  }
+  double a[32], x[32], dinv = 1.0;
   bool bad = false;
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    if (k < m) {
-      const double dkk = readlane_f64(a[k], k);
-      bad = bad || !(dkk > 0.0);
-      const double piv = sqrt(dkk), inv = 1.0 / piv;
-      a[k] = (lane == k) ? piv : a[k] * inv;
-#pragma unroll
-      for (int j = k + 1; j < 32; ++j) {
-        if (j < m) a[j] -= a[k] * readlane_f64(a[k], j);
-      }
-    }
-  }
+  WAVE_CHOL_CORE(S, m, lane, a, x, dinv, bad)
   if (bad && lane == 0) *fail = 1;
-  double x = (lane < m) ? b[lane] : 0.0;
+  double u = (lane < m) ? b[lane] : 0.0;
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
     if (k < m) {
-      const double xk = readlane_f64(x, k) / readlane_f64(a[k], k);
-      x = (lane == k) ? xk : ((lane > k) ? x - a[k] * xk : x);
+      const double uk = readlane_f64(u, k) * readlane_f64(dinv, k);
+      u = (lane == k) ? uk : ((lane > k) ? u - a[k] * uk : u);
     }
   }
-  x += (lane < m) ? z[lane] : 0.0;
-  double wv_ = 0.0;   // solved entries, lane i holds w_i once k <= i has been processed
+  u += (lane < m) ? z[lane] : 0.0;
+  double wj = 0.0;
 #pragma unroll
-  for (int k = 31; k >= 0; --k) {
-    if (k < m) {
-      double part = (lane > k && lane < m) ? a[k] * wv_ : 0.0;   // L[i][k] w_i, i > k
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-      const double wk = (readlane_f64(x, k) - part) / readlane_f64(a[k], k);
-      wv_ = (lane == k) ? wk : wv_;
-    }
-  }
-  if (lane < m) wout[lane] = wv_;
+  for (int i = 0; i < 32; ++i)
+    if (i < m) wj += x[i] * readlane_f64(u, i);   // x[i] = Li[i][lane], zero for i < lane
+  if (lane < m) wout[lane] = wj;
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1211,8 +1189,41 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
       bv[i] = a + tsq[i] * yx[i];
     }
     __syncthreads();
-    if (wid == 0) wave_chol_solve_32(S, M, bv, zc, wv + P, &s_fail, lane);
-    __syncthreads();
+  }
+  // Gram part of the message records, [ N_a' N_a ] + the children's records (spamtree_model.cpp:1158-1207): it does
+  // not depend on the draw, so in a reference group waves 1..3 form it while wave 0 factorises and solves
+  double *rec = A.acc + B0.acc_off;
+  const int nsteps = Mr4 >> 2;
+  if (refgrp && wid == 0) {
+    wave_chol_solve_32(S, M, bv, zc, wv + P, &s_fail, lane);
+  } else {
+    const int w0 = refgrp ? wid - 1 : wid, nw = refgrp ? 3 : 4;
+    for (int u = w0; u < J * 4; u += nw) {
+      const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
+      const int ma = s_am[t], oa = s_ao[t];
+      if (it * 16 >= ma || jt * 16 >= ma) continue;
+      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+      const double *ap = Np + (size_t)l4 * ldN + oa + it * 16 + l15;
+      const double *bp = Np + (size_t)l4 * ldN + oa + jt * 16 + l15;
+      for (int st = 0; st < nsteps; ++st) {
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], c, 0, 0, 0);
+        ap += 4 * ldN; bp += 4 * ldN;
+      }
+      double *out = rec + s_aoff[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+        if (i < ma && j < ma) {
+          double v = c[r];
+          for (int cc = 0; cc < s_nch; ++cc) v += A.acc[s_coff[cc] + s_aoff[t] + i * ma + j];
+          out[i * ma + j] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (refgrp) {
+    const double *Ri = Np + P;
     if (tid < M) {
       const int i = tid;
       A.w[G.row0 + i] = wv[P + i];
@@ -1248,31 +1259,7 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
     av[idx] = a;
   }
   __syncthreads();
-  // message record per ancestor: [ N_a' N_a | -N_a' av_a ] + the children's records   (spamtree_model.cpp:1158-1207)
-  double *rec = A.acc + B0.acc_off;
-  const int nsteps = Mr4 >> 2;
-  for (int u = wid; u < J * 4; u += NT / 64) {
-    const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
-    const int ma = s_am[t], oa = s_ao[t];
-    if (it * 16 >= ma || jt * 16 >= ma) continue;
-    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-    const double *ap = Np + (size_t)l4 * ldN + oa + it * 16 + l15;
-    const double *bp = Np + (size_t)l4 * ldN + oa + jt * 16 + l15;
-    for (int st = 0; st < nsteps; ++st) {
-      c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], c, 0, 0, 0);
-      ap += 4 * ldN; bp += 4 * ldN;
-    }
-    double *out = rec + s_aoff[t];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-      if (i < ma && j < ma) {
-        double v = c[r];
-        for (int cc = 0; cc < s_nch; ++cc) v += A.acc[s_coff[cc] + s_aoff[t] + i * ma + j];
-        out[i * ma + j] = v;
-      }
-    }
-  }
+  // vector part of the records: -N_a' av_a + the children's
   for (int idx = tid; idx < J * 32; idx += NT) {
     const int t = idx >> 5, i = idx & 31;
     const int ma = s_am[t], oa = s_ao[t];
