@@ -387,70 +387,82 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 // shared core: in-register Cholesky (lane i owns row i) followed by the columns of L^{-1} (lane j owns column j).
 // dinv = 1 / L[lane][lane].  Divisions and square roots are replaced by one rsqrt per pivot.
-#define WAVE_CHOL_CORE(SRC, m, lane, a, x, dinv, bad)                                                         \
-  {                                                                                                           \
-    const int li_ = min(lane, (m) - 1);                                                                       \
-    _Pragma("unroll") for (int j = 0; j < 32; ++j) {                                                          \
-      const double v_ = (SRC)[li_ * (m) + min(j, (m) - 1)];                                                   \
-      a[j] = (lane < (m) && j <= lane) ? v_ : ((j == lane) ? 1.0 : 0.0);                                      \
-    }                                                                                                         \
-    _Pragma("unroll") for (int k = 0; k < 32; ++k) {                                                          \
-      if (k < (m)) {                                                                                          \
-        const double dkk_ = readlane_f64(a[k], k);                                                            \
-        bad = bad || !(dkk_ > 0.0);                                                                           \
-        const double rs_ = rsqrt(dkk_);                                                                       \
-        a[k] = (lane == k) ? dkk_ * rs_ : a[k] * rs_;                                                         \
-        dinv = (lane == k) ? rs_ : dinv;                                                                      \
-        _Pragma("unroll") for (int j = k + 1; j < 32; ++j) {                                                  \
-          if (j < (m)) a[j] -= a[k] * readlane_f64(a[k], j);                                                  \
-        }                                                                                                     \
-      }                                                                                                       \
-    }                                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 32; ++i) {                                                          \
-      double sacc_ = (i == lane) ? 1.0 : 0.0;                                                                 \
-      if (i < (m)) {                                                                                          \
-        _Pragma("unroll") for (int k = 0; k < i; ++k) sacc_ -= readlane_f64(a[k], i) * x[k];                  \
-        sacc_ *= readlane_f64(dinv, i);                                                                       \
-      }                                                                                                       \
-      x[i] = sacc_;                                                                                           \
-    }                                                                                                         \
+// MM = compile-time bound (m <= MM <= 32, rows/columns in [m, MM) are identity padding): no per-iteration branches.
+template <int MM>
+__device__ __forceinline__ void wave_chol_core(const double *SRC, int m, int lane, double (&a)[32], double (&x)[32], double &dinv, bool &bad) {
+  const int li = min(lane, m - 1);
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    const double v = SRC[li * m + min(j, m - 1)];
+    a[j] = (lane < m && j <= lane && j < m) ? v : ((j == lane) ? 1.0 : 0.0);
   }
+#pragma unroll
+  for (int k = 0; k < MM; ++k) {
+    const double dkk = readlane_f64(a[k], k);
+    bad = bad || !(dkk > 0.0);
+    const double rs = rsqrt(dkk);
+    a[k] = (lane == k) ? dkk * rs : a[k] * rs;
+    dinv = (lane == k) ? rs : dinv;
+#pragma unroll
+    for (int j = k + 1; j < MM; ++j) a[j] -= a[k] * readlane_f64(a[k], j);
+  }
+#pragma unroll
+  for (int i = 0; i < MM; ++i) {
+    double sacc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) sacc -= readlane_f64(a[k], i) * x[k];
+    x[i] = sacc * readlane_f64(dinv, i);
+  }
+}
 
-__device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fail, int lane) {
+template <int MM>
+__device__ void wave_chol_inverse_t(const double *R, int m, double *Ri, int *fail, int lane) {
   double a[32], x[32], dinv = 1.0;
   bool bad = false;
-  WAVE_CHOL_CORE(R, m, lane, a, x, dinv, bad)
+  wave_chol_core<MM>(R, m, lane, a, x, dinv, bad);
   if (bad && lane == 0) *fail = 1;
   if (lane < m) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i)
+    for (int i = 0; i < MM; ++i)
       if (i < m) Ri[i * m + lane] = (i >= lane) ? x[i] : 0.0;
   }
+}
+__device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fail, int lane) {
+  if (m <= 8) wave_chol_inverse_t<8>(R, m, Ri, fail, lane);
+  else if (m <= 16) wave_chol_inverse_t<16>(R, m, Ri, fail, lane);
+  else if (m <= 24) wave_chol_inverse_t<24>(R, m, Ri, fail, lane);
+  else if (m <= 28) wave_chol_inverse_t<28>(R, m, Ri, fail, lane);
+  else wave_chol_inverse_t<32>(R, m, Ri, fail, lane);
 }
 
 // Cholesky of S (m x m, m <= 32, LDS row-major, lower triangle valid) by one wave in registers, then
 // w = L^{-T} (L^{-1} b + z): the block-Gibbs draw of spamtree_model.cpp:1054, 1086.  The forward solve is column
 // oriented (broadcast of the solved entry); the transposed solve uses the columns of L^{-1}, so no cross-lane
 // reduction is needed: w_j = sum_i Li[i][j] u_i.
-__device__ void wave_chol_solve_32(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
+template <int MM>
+__device__ void wave_chol_solve_t(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
   double a[32], x[32], dinv = 1.0;
   bool bad = false;
-  WAVE_CHOL_CORE(S, m, lane, a, x, dinv, bad)
+  wave_chol_core<MM>(S, m, lane, a, x, dinv, bad);
   if (bad && lane == 0) *fail = 1;
   double u = (lane < m) ? b[lane] : 0.0;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    if (k < m) {
-      const double uk = readlane_f64(u, k) * readlane_f64(dinv, k);
-      u = (lane == k) ? uk : ((lane > k) ? u - a[k] * uk : u);
-    }
+  for (int k = 0; k < MM; ++k) {
+    const double uk = readlane_f64(u, k) * readlane_f64(dinv, k);
+    u = (lane == k) ? uk : ((lane > k) ? u - a[k] * uk : u);
   }
   u += (lane < m) ? z[lane] : 0.0;
   double wj = 0.0;
 #pragma unroll
-  for (int i = 0; i < 32; ++i)
-    if (i < m) wj += x[i] * readlane_f64(u, i);   // x[i] = Li[i][lane], zero for i < lane
+  for (int i = 0; i < MM; ++i) wj += x[i] * readlane_f64(u, i);   // x[i] = Li[i][lane], zero for i < lane
   if (lane < m) wout[lane] = wj;
+}
+__device__ void wave_chol_solve_32(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
+  if (m <= 8) wave_chol_solve_t<8>(S, m, b, z, wout, fail, lane);
+  else if (m <= 16) wave_chol_solve_t<16>(S, m, b, z, wout, fail, lane);
+  else if (m <= 24) wave_chol_solve_t<24>(S, m, b, z, wout, fail, lane);
+  else if (m <= 28) wave_chol_solve_t<28>(S, m, b, z, wout, fail, lane);
+  else wave_chol_solve_t<32>(S, m, b, z, wout, fail, lane);
 }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1061,7 +1073,7 @@ struct SampleFastArgs {
   double tausq_inv[QMAX];
 };
 
-__global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
+__global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
@@ -1091,6 +1103,7 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
   const Blk B0 = A.blks[G.blk0];
   const int J = B0.nanc;
   const bool refgrp = B0.isref != 0;
+  STAMP_DECL
   if (tid < J) {
     const int a = A.anc_idx[B0.anc_ptr + tid];
     s_am[tid] = A.blks[a].m;
@@ -1124,6 +1137,7 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
   __syncthreads();
   for (int t = 0; t < J; ++t)
     for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[s_arow[t] + i];
+  STAMP(0);
   // panel rows -> LDS (row j of the group = one panel row of its block); pad rows / columns zero.
   // Each wave takes rows wid, wid+4, ...; all loads of four rows are issued before the first LDS store.
   const int rowlen = P + (refgrp ? M : 1);
@@ -1161,6 +1175,7 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
     for (int k = 256 + lane; k < rowlen; k += 64) Np[(size_t)j * ldN + k] = src[k];
   }
   __syncthreads();
+  STAMP(1);
   for (int j = wid; j < M; j += NT / 64) {
     double a = 0.0;
     const double *row = Np + (size_t)j * ldN;
@@ -1169,6 +1184,7 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
     if (lane == 0) tv[j] = a;
   }
   __syncthreads();
+  STAMP(2);
   if (refgrp) {
     const double *Ri = Np + P;   // Ri[i][j] = Np[i*ldN + P + j]
     for (int idx = tid; idx < M * M; idx += NT) {
@@ -1190,12 +1206,14 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
     }
     __syncthreads();
   }
+  STAMP(3);
   // Gram part of the message records, [ N_a' N_a ] + the children's records (spamtree_model.cpp:1158-1207): it does
   // not depend on the draw, so in a reference group waves 1..3 form it while wave 0 factorises and solves
   double *rec = A.acc + B0.acc_off;
   const int nsteps = Mr4 >> 2;
   if (refgrp && wid == 0) {
     wave_chol_solve_32(S, M, bv, zc, wv + P, &s_fail, lane);
+    STAMP(7);
   } else {
     const int w0 = refgrp ? wid - 1 : wid, nw = refgrp ? 3 : 4;
     for (int u = w0; u < J * 4; u += nw) {
@@ -1210,18 +1228,33 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
         ap += 4 * ldN; bp += 4 * ldN;
       }
       double *out = rec + s_aoff[t];
+      // children's records: all loads of a chunk of four children are issued together (fixed summation order)
+      double chv[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c0 = 0; c0 < s_nch; c0 += 4) {
+        double ld4[4][4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+            ld4[cc][r] = (c0 + cc < s_nch && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + s_aoff[t] + i * ma + j] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) chv[r] += ld4[cc][r];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-        if (i < ma && j < ma) {
-          double v = c[r];
-          for (int cc = 0; cc < s_nch; ++cc) v += A.acc[s_coff[cc] + s_aoff[t] + i * ma + j];
-          out[i * ma + j] = v;
-        }
+        if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
       }
     }
   }
   __syncthreads();
+  STAMP(4);
   if (refgrp) {
     const double *Ri = Np + P;
     if (tid < M) {
@@ -1259,6 +1292,7 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
     av[idx] = a;
   }
   __syncthreads();
+  STAMP(5);
   // vector part of the records: -N_a' av_a + the children's
   for (int idx = tid; idx < J * 32; idx += NT) {
     const int t = idx >> 5, i = idx & 31;
@@ -1270,6 +1304,8 @@ __global__ __launch_bounds__(NT) void k_sample_mfma(SampleFastArgs A) {
       rec[s_aoff[t] + ma * ma + i] = a;
     }
   }
+  STAMP(6);
+  STAMP_FLUSH;
   if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
 }
 
