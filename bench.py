@@ -38,7 +38,8 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
     the n=1e6 workload with the reference's own cost law.  Allocation/page-touch of its caches is not timed."""
     from oracle.refcpu import RefCpu
     from spamtree_amd.synthetic import make_workload
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-CPU share; the reference's README runs num_threads = 10
+    cores = int(os.environ.get("SPAMTREE_CPU_THREADS", min(os.cpu_count() or 1, 16)))
     wl = make_workload(side)
     rc = RefCpu(wl["y"], wl["X"], wl["coords"], wl["mv_id"], wl["res_is_ref"], wl["parents"], wl["children"],
                 wl["block_names"], wl["block_groups"], wl["indexing"], threads=cores)
@@ -54,7 +55,7 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
         rc.stats()
         its += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget or its >= 50:
+        if dt > seconds_budget or its >= 400:
             break
     rc.close()
     ratio = reference_cost(wl) / reference_cost(full_wl)
@@ -73,7 +74,7 @@ def main():
     ap.add_argument("--side", type=int, default=1000, help="grid side; n = side^2 (1000 -> config #3, 316 -> #2)")
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-side", type=int, default=224, help="grid side of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-side", type=int, default=316, help="grid side of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,6 +147,15 @@ def main():
     bytes_per_launch = alg["A"] / n_levels * share
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     it_s = args.steps / dt
+    # HBM bytes per k_factor launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the workload it was taken on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_mfma_pmc_hbm.json")))
+        if world == 1 and args.side == 1000 and args.q == 1:
+            traffic = pmc["summary"]["k_factor_mfma"]["hbm_bytes_per_launch"]
+    except Exception:      # noqa: BLE001
+        traffic = None
     out = {
         "metric": "Gibbs iterations/sec + achieved HBM GB/s, n=1e6 grid, 1/2/4/8 MI355X",
         "value": it_s, "unit": "Gibbs iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -160,7 +170,7 @@ def main():
                        alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_factor (phase A: covariance build + chain solve + Cholesky)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_ms": avg_launch_ms, "launches": fac_n,
+                     "traffic": traffic, "avg_launch_ms": avg_launch_ms, "launches": fac_n,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "whole_iteration_GBps": alg["total"] / (dt / args.steps) / 1e9,
                      "by_level_ms": [round(float(x), 4) for x in lvl_ms],
