@@ -67,7 +67,9 @@ typedef struct st_options {
   int32_t rank;                /* multi-GPU: this process' rank ...                                                */
   int32_t world;               /* ... of `world` processes sharing one problem (1 = single GPU); see the end of this file */
   int32_t force_generic;       /* 1 = use the global-scratch kernels even where the LDS kernels fit (testing)      */
-  int32_t reserved;
+  int32_t reserved;            /* bit 0: recompute the theta-only Gram part of the messages on every sweep, as the
+                                  reference does (need_update is always true, spamtree_fit.cpp:184); default 0 caches it
+                                  per accepted theta -- identical values                               */
 } st_options;
 
 /* ---- lifetime: SpamTreeMV::SpamTreeMV (spamtree_model.cpp:8-192) incl. init_indexing/init_finalize/init_model_data */

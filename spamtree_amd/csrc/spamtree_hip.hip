@@ -882,6 +882,7 @@ struct SampleArgs {
   double *scratch;       // BIG: staged S matrix
   long long scratch_stride;
   int maxP, maxM, maxLd;
+  int do_gram;
   double tausq_inv[QMAX];
 };
 
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       }
       __syncthreads();
       double *out = A.acc + B.acc_off + off;
-      for (int idx = tid; idx < ma * ma + ma; idx += NT) {
+      for (int idx = A.do_gram ? tid : ma * ma + tid; idx < ma * ma + ma; idx += NT) {
         double acc = 0.0;
         if (idx < ma * ma) {
           const int i = idx / ma, j = idx - i * ma;
@@ -1070,6 +1071,7 @@ struct SampleFastArgs {
   double *acc;
   int *errflag;
   int ldN, Mr4, maxP;
+  int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
   double tausq_inv[QMAX];
 };
 
@@ -1214,7 +1216,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   if (refgrp && wid == 0) {
     wave_chol_solve_32(S, M, bv, zc, wv + P, &s_fail, lane);
     STAMP(7);
-  } else {
+  } else if (A.do_gram) {
     const int w0 = refgrp ? wid - 1 : wid, nw = refgrp ? 3 : 4;
     for (int u = w0; u < J * 4; u += nw) {
       const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
@@ -1510,6 +1512,8 @@ struct st_handle_s {
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
   std::vector<std::pair<long long, long long>> top_zero;   // sub-ranges of it owned by other ranks
   bool ext_stream = false;
+  bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
+  bool cache_gram = true;
   ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
   std::vector<LevelInfo> levels;
   LevelInfo pred_info;
@@ -1657,6 +1661,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   h->device = opt ? opt->device : 0;
   h->quirks = opt ? opt->reference_quirks : 1;
   h->force_generic = opt ? opt->force_generic : 0;
+  h->cache_gram = !(opt && (opt->reserved & 1));
   const long long n = pb->n_all, nb = pb->n_blocks;
   h->n_all = n; h->n_blocks = nb; h->q = pb->q; h->p = pb->p; h->d = pb->d; h->n_groups = pb->n_groups;
   for (int j = 0; j < QMAX; ++j) h->tausq_inv[j] = 1.0;
@@ -2182,6 +2187,7 @@ extern "C" int st_swap(st_handle h) {
   if (!h) return ST_ERR_USAGE;
   std::swap(h->slot_map[0], h->slot_map[1]);
   std::swap(h->theta[0], h->theta[1]);
+  h->gram_valid = false;
   return ST_OK;
 }
 extern "C" int st_synchronize(st_handle h) {
@@ -2317,6 +2323,7 @@ extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int n
   int rc = make_covpar(h, theta, ntheta, &cp);
   if (rc) return rc;
   h->theta[slot].assign(theta, theta + ntheta);
+  if (slot == 0) h->gram_valid = false;
   rc = reset_err(h);
   if (rc) return rc;
   return factor_launch(h, h->slot_map[slot], cp);
@@ -2434,11 +2441,13 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
     A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.y = h->d_y.p; A.xb = h->d_xb.p; A.z = h->d_z.p; A.mv = h->d_mv.p;
     A.obs = h->d_obs.p; A.acc = h->d_acc.p; A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxLd = L.maxLd;
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
+    A.do_gram = (h->gram_valid && h->cache_gram) ? 0 : 1;
     {
       ProfScope ps(h, 1);
       if (L.fast) {
         SampleFastArgs F;
         std::memset(&F, 0, sizeof(F));
+        F.do_gram = A.do_gram;
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.maxP = L.maxP;
@@ -2480,7 +2489,9 @@ extern "C" int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len) {
 extern "C" int st_sample_w_top(st_handle h) {   // the replicated levels above the cut
   if (!h) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
-  return sample_launch(h, std::min(h->cut, h->n_actual_groups), 0);
+  const int rc = sample_launch(h, std::min(h->cut, h->n_actual_groups), 0);
+  if (rc == ST_OK) h->gram_valid = true;   // every record now carries the Gram sums of the accepted theta
+  return rc;
 }
 extern "C" int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len) {
   if (!h) return ST_ERR_USAGE;

@@ -141,3 +141,26 @@ def test_generated_sweep_normals_are_the_documented_stream():
     hm.deal_with_w(None, seed=77, it=3)
     assert relerr(hm.get_w(), om.w) <= REL
     hm.close()
+
+
+def test_gram_cache_gives_identical_sweeps():
+    """caching the theta-only part of the messages per accepted theta must not change a single bit."""
+    pb = make_problem(side=40, q=1, seed=21, random_coords=True)
+    rng = np.random.default_rng(1)
+    a = hip_model(pb, tausq=0.2)
+    b = hip_model(pb, tausq=0.2, cache_gram=False)
+    assert a.get_loglik_comps_w(0) and b.get_loglik_comps_w(0)
+    for it in range(3):
+        z = rng.standard_normal(pb["n"])
+        a.deal_with_w(z); b.deal_with_w(z)
+        assert np.array_equal(a.get_w(), b.get_w())
+    th2 = pb["theta"] * 1.02
+    for m in (a, b):
+        m.theta_update(1, th2)
+        assert m.get_loglik_comps_w(1)
+        m.accept_make_change()
+    for it in range(2):
+        z = rng.standard_normal(pb["n"])
+        a.deal_with_w(z); b.deal_with_w(z)
+        assert np.array_equal(a.get_w(), b.get_w())
+    a.close(); b.close()
