@@ -136,6 +136,19 @@ int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, doubl
 int st_synchronize(st_handle h);
 void *st_stream(st_handle h);                              /* the hipStream_t every kernel is launched on */
 
+/* ---- SURVEY.md section 8f "next" rows -------------------------------------------------------------------------------
+ * CrossCovarianceAG10 (/root/reference/src/covariance_functions.cpp:301-355, exported to R, NAMESPACE:14): dense
+ * n1 x n2 Apanasovich-Genton cross-covariance, column-major; coords n x 2 column-major, mv 1-based, Dmat q x q.
+ * Needs no handle.  q < 2 is refused like the reference ("Invalid Dmat for multivariate data"). */
+int st_cross_covariance_ag10(const double *coords1, const int64_t *mv1, int64_t n1, const double *coords2, const int64_t *mv2,
+                             int64_t n2, const double *ai1, const double *ai2, const double *phi_i, const double *thetamv,
+                             const double *Dmat, int32_t q, int32_t device, double *out);
+/* Running posterior means of w and yhat on the device (what list_mean, /root/reference/src/list_mean.cpp:10-40, computes
+ * after the fact from `keep` stored copies): accumulate on every saved iteration, read the means once. */
+int st_summary_reset(st_handle h);
+int st_summary_accumulate(st_handle h, uint64_t seed, uint32_t iter);
+int st_summary_get(st_handle h, double *w_mean, double *yhat_mean, int64_t *n_accumulated);
+
 int st_set_stream(st_handle h, void *stream);              /* launch on the caller's stream (the one its collectives use) */
 
 /* ---- multi-GPU (st_options.world > 1): one process per GPU shares ONE problem.

@@ -63,6 +63,11 @@ SIGNATURES = {
     "st_sample_w_top": (C.c_int, [H]),
     "st_mg_pack_w": (C.c_int, [H, C.POINTER(C.c_void_p), c_ip]),
     "st_mg_unpack_w": (C.c_int, [H]),
+    "st_cross_covariance_ag10": (C.c_int, [c_dp, c_ip, C.c_int64, c_dp, c_ip, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32,
+                                           C.c_int32, c_dp]),
+    "st_summary_reset": (C.c_int, [H]),
+    "st_summary_accumulate": (C.c_int, [H, C.c_uint64, C.c_uint32]),
+    "st_summary_get": (C.c_int, [H, c_dp, c_dp, c_ip]),
     "st_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int32]),
     "st_comm_init": (C.c_int, [H, C.c_void_p]),
 }

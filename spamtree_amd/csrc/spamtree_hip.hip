@@ -1446,6 +1446,22 @@ __global__ void k_yhat(const double *xb, const double *w, const double *noise, c
   if (i < n) yhat[i] = xb[i] + w[i] + noise[i] / sqrt(tsq_inv_q[mv[i]]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Next" rows of SURVEY.md section 8f: the exported CrossCovarianceAG10 (covariance_functions.cpp:301-355) and
+// running posterior means of w / yhat over saved iterations (the use of list_mean, list_mean.cpp:10-40)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_cross_cov(const double *c1, const int *mv1, long long n1, const double *c2, const int *mv2, long long n2, CovPar cp,
+                            double *out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long j = blockIdx.y;
+  if (i < n1 && j < n2) out[j * n1 + i] = cov_entry(cp, c1[i], c1[n1 + i], mv1[i], c2[j], c2[n2 + j], mv2[j]);
+}
+__global__ void k_axpy_sum(double *acc, const double *x, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += x[i];
+}
+
 // ===============================================================================================================
 // host side
 // ===============================================================================================================
@@ -1512,6 +1528,8 @@ struct st_handle_s {
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
   std::vector<std::pair<long long, long long>> top_zero;   // sub-ranges of it owned by other ranks
   bool ext_stream = false;
+  DevBuf<double> d_sum_w, d_sum_yhat;         // running sums over saved iterations (st_summary_*)
+  long long n_summary = 0;
   bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
   bool cache_gram = true;
   ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
@@ -1625,7 +1643,7 @@ extern "C" int st_destroy(st_handle h) {
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
   h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free();
-  h->d_ownobs.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free();
+  h->d_ownobs.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -2736,5 +2754,74 @@ extern "C" int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_l
     if (bytes_by_level) bytes_by_level[g] = h->levels[g].alg_bytes_A;
     h->prof_level_ms[g] = 0.0; h->prof_level_n[g] = 0;
   }
+  return ST_OK;
+}
+
+// ---- CrossCovarianceAG10 (covariance_functions.cpp:301-355): dense n1 x n2 cross-covariance, column-major output.
+// mv1 / mv2 are 1-based (as in R).  Like the reference it refuses a 1 x 1 Dmat ("Invalid Dmat for multivariate data").
+extern "C" int st_cross_covariance_ag10(const double *coords1, const int64_t *mv1, int64_t n1, const double *coords2, const int64_t *mv2,
+                                        int64_t n2, const double *ai1, const double *ai2, const double *phi_i, const double *thetamv,
+                                        const double *Dmat, int32_t q, int32_t device, double *out) {
+  if (!coords1 || !coords2 || !mv1 || !mv2 || !out || !Dmat || q < 2 || q > QMAX) {
+    g_create_error = q < 2 ? "Invalid Dmat for multivariate data" : "st_cross_covariance_ag10: bad argument";
+    return ST_ERR_USAGE;
+  }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "no usable HIP device"; return ST_ERR_HIP; }
+  CovPar cp;
+  std::memset(&cp, 0, sizeof(cp));
+  cp.q = q; cp.ncb = q > 2 ? 3 : 1;
+  for (int j = 0; j < q; ++j) { cp.ai1[j] = ai1[j]; cp.ai2[j] = ai2[j]; cp.phi[j] = phi_i[j]; }
+  for (int j = 0; j < cp.ncb; ++j) cp.tmv[j] = thetamv[j];
+  for (int i = 0; i < q * q; ++i) cp.D[i] = Dmat[i];   // symmetric: layout irrelevant
+  std::vector<int> m1(n1), m2(n2);
+  for (int64_t i = 0; i < n1; ++i) { m1[i] = (int)mv1[i] - 1; if (m1[i] < 0 || m1[i] >= q) { g_create_error = "mv1 out of range"; return ST_ERR_USAGE; } }
+  for (int64_t i = 0; i < n2; ++i) { m2[i] = (int)mv2[i] - 1; if (m2[i] < 0 || m2[i] >= q) { g_create_error = "mv2 out of range"; return ST_ERR_USAGE; } }
+  DevBuf<double> d1, d2, dout;
+  DevBuf<int> dm1, dm2;
+  int rc = ST_OK;
+  auto bad = [&](hipError_t e) { if (e != hipSuccess) { g_create_error = hipGetErrorString(e); rc = ST_ERR_HIP; } return e != hipSuccess; };
+  if (!bad(d1.alloc(2 * n1)) && !bad(d2.alloc(2 * n2)) && !bad(dout.alloc((size_t)n1 * n2)) && !bad(dm1.upload(m1)) && !bad(dm2.upload(m2)) &&
+      !bad(hipMemcpy(d1.p, coords1, 2 * n1 * sizeof(double), hipMemcpyHostToDevice)) &&
+      !bad(hipMemcpy(d2.p, coords2, 2 * n2 * sizeof(double), hipMemcpyHostToDevice))) {
+    hipLaunchKernelGGL(k_cross_cov, dim3((unsigned)((n1 + NT - 1) / NT), (unsigned)n2), dim3(NT), 0, 0, d1.p, dm1.p, (long long)n1, d2.p, dm2.p,
+                       (long long)n2, cp, dout.p);
+    if (!bad(hipGetLastError())) bad(hipMemcpy(out, dout.p, (size_t)n1 * n2 * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  d1.free(); d2.free(); dout.free(); dm1.free(); dm2.free();
+  return rc;
+}
+
+// ---- running posterior means on device: call st_summary_accumulate on every saved iteration
+extern "C" int st_summary_reset(st_handle h) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  if (!h->d_sum_w.p) { HCHK(h, h->d_sum_w.alloc(h->n_all)); HCHK(h, h->d_sum_yhat.alloc(h->n_all)); }
+  HCHK(h, hipMemsetAsync(h->d_sum_w.p, 0, h->n_all * sizeof(double), h->stream));
+  HCHK(h, hipMemsetAsync(h->d_sum_yhat.p, 0, h->n_all * sizeof(double), h->stream));
+  h->n_summary = 0;
+  return ST_OK;
+}
+extern "C" int st_summary_accumulate(st_handle h, uint64_t seed, uint32_t iter) {   // yhat noise: device stream 5 (spamtree_fit.cpp:384)
+  if (!h) return ST_ERR_USAGE;
+  if (!h->d_sum_w.p) { const int rc0 = st_summary_reset(h); if (rc0) return rc0; }
+  HCHK(h, hipSetDevice(h->device));
+  int rc = gen_or_upload_z(h, nullptr, seed, iter, 5u, h->d_tmp_n.p);
+  if (rc) return rc;
+  const int grid = (int)((h->n_all + NT - 1) / NT);
+  hipLaunchKernelGGL(k_yhat, dim3(grid), dim3(NT), 0, h->stream, h->d_xb.p, h->d_w.p, h->d_tmp_n.p, h->d_mv.p, h->n_all, h->d_tsq.p, h->d_tmp_n.p);
+  hipLaunchKernelGGL(k_axpy_sum, dim3(grid), dim3(NT), 0, h->stream, h->d_sum_yhat.p, h->d_tmp_n.p, h->n_all);
+  hipLaunchKernelGGL(k_axpy_sum, dim3(grid), dim3(NT), 0, h->stream, h->d_sum_w.p, h->d_w.p, h->n_all);
+  HCHK(h, hipGetLastError());
+  h->n_summary += 1;
+  return ST_OK;
+}
+extern "C" int st_summary_get(st_handle h, double *w_mean, double *yhat_mean, int64_t *n_accumulated) {
+  if (!h) return ST_ERR_USAGE;
+  if (n_accumulated) *n_accumulated = h->n_summary;
+  if (h->n_summary == 0 || !h->d_sum_w.p) { h->err = "no iteration accumulated"; return ST_ERR_USAGE; }
+  HCHK(h, hipSetDevice(h->device));
+  const double inv = 1.0 / (double)h->n_summary;
+  if (w_mean) { int rc = download_rows(h, h->d_sum_w.p, w_mean); if (rc) return rc; for (long long i = 0; i < h->n_all; ++i) w_mean[i] *= inv; }
+  if (yhat_mean) { int rc = download_rows(h, h->d_sum_yhat.p, yhat_mean); if (rc) return rc; for (long long i = 0; i < h->n_all; ++i) yhat_mean[i] *= inv; }
   return ST_OK;
 }

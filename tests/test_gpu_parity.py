@@ -164,3 +164,48 @@ def test_gram_cache_gives_identical_sweeps():
         a.deal_with_w(z); b.deal_with_w(z)
         assert np.array_equal(a.get_w(), b.get_w())
     a.close(); b.close()
+
+
+def test_cross_covariance_ag10_export():
+    """man/CrossCovarianceAG10.Rd:72-93 inputs (q = 2) and a q = 3 parameter set, device vs oracle (itself pinned by mpmath)."""
+    from oracle import spamtree_oracle as so
+    from spamtree_amd.covariance import CrossCovarianceAG10
+    from spamtree_amd.model import SpamTreeError
+    from tests.util import nice_theta
+    xl = np.linspace(0.0, 1.0, 10)
+    g = np.array([(a, b) for b in xl for a in xl])
+    cx = np.vstack([g, g])
+    mv = np.repeat([1, 2], 100)
+    D = np.array([[0, 1.0], [1.0, 0]])
+    got = CrossCovarianceAG10(cx, mv, cx, mv, [1, 1.5], [.1, .51], [1, 2], [5], D)
+    ref = so.CrossCovarianceAG10(cx, mv, cx, mv, [1, 1.5], [.1, .51], [1, 2], [5], D)
+    assert got.shape == (200, 200) and np.abs(got - ref).max() <= 1e-14 * np.abs(ref).max()
+    cp = so.CovarianceParams(2, 3, -1)
+    cp.transform(nice_theta(3))
+    rng = np.random.default_rng(2)
+    p1, p2 = rng.uniform(size=(70, 2)), rng.uniform(size=(55, 2))
+    m1, m2 = rng.integers(1, 4, 70), rng.integers(1, 4, 55)
+    got = CrossCovarianceAG10(p1, m1, p2, m2, cp.ai1, cp.ai2, cp.phi_i, cp.thetamv, cp.Dmat)
+    ref = so.CrossCovarianceAG10(p1, m1, p2, m2, cp.ai1, cp.ai2, cp.phi_i, cp.thetamv, cp.Dmat)
+    assert np.abs(got - ref).max() <= 1e-14 * np.abs(ref).max()
+    with pytest.raises(SpamTreeError):                      # the reference stops: "Invalid Dmat for multivariate data"
+        CrossCovarianceAG10(p1, np.ones(70), p2, np.ones(55), [1.0], [0.1], [1.0], [5.0], np.zeros((1, 1)))
+
+
+def test_running_posterior_means():
+    import ctypes as C
+    from spamtree_amd.model import _dp
+    pb = make_problem(side=25, q=1, seed=8, missing=0.1)
+    hm = hip_model(pb, tausq=0.2)
+    assert hm.get_loglik_comps_w(0)
+    ws, ys = [], []
+    assert hm.lib.st_summary_reset(hm.h) == 0
+    for it in range(4):
+        hm.deal_with_w(None, seed=3, it=it)
+        ws.append(hm.get_w().copy()); ys.append(hm.yhat(None, seed=3, it=it))
+        assert hm.lib.st_summary_accumulate(hm.h, 3, it) == 0
+    wm, ym = np.zeros(pb["n"]), np.zeros(pb["n"])
+    cnt = C.c_int64()
+    assert hm.lib.st_summary_get(hm.h, _dp(wm), _dp(ym), C.byref(cnt)) == 0 and cnt.value == 4
+    assert np.abs(wm - np.mean(ws, axis=0)).max() < 1e-13 and np.abs(ym - np.mean(ys, axis=0)).max() < 1e-13
+    hm.close()
