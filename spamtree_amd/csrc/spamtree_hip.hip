@@ -465,6 +465,47 @@ __device__ void wave_chol_solve_32(const double *S, int m, const double *b, cons
   else wave_chol_solve_t<32>(S, m, b, z, wout, fail, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Workgroup-wide (NT = 256 threads) right-looking Cholesky of an m x m (m <= 32) SPD matrix in LDS with the forward
+// elimination of a right-hand side carried along: thread (ti, tj) = (tid / 32, tid % 32) updates rows k+1+ti, +8, ...
+// of column tj.  Two barriers per pivot; the pivot reciprocal square roots end in rsd[].
+//   A  : m x m, row stride 33, lower triangle valid on entry; holds L (scaled columns) on exit
+//   Bm : identity on entry -> L^{-1} on exit (rows k finalised at pivot k), row stride 33; may be null
+//   u  : right-hand side -> L^{-1} u on exit; may be null
+// ---------------------------------------------------------------------------------------------------------------
+#define CH_LD 33
+__device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, double *col, double *xrow, double *rsd, int *fail) {
+  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
+  for (int k = 0; k < m; ++k) {
+    __syncthreads();
+    const double d = A[k * CH_LD + k];
+    if (!(d > 0.0) && tid == 0) *fail = 1;
+    const double rs = rsqrt(d);
+    if (tid < m) {
+      if (tid > k) col[tid] = A[tid * CH_LD + k] * rs;
+      else if (Bm) xrow[tid] = Bm[k * CH_LD + tid] * rs;
+    }
+    if (tid == 32) { rsd[k] = rs; if (u) xrow[32] = u[k] * rs; }
+    __syncthreads();
+    for (int i = k + 1 + ti; i < m; i += 8) {
+      const double ci = col[i];
+      if (tj > k) {
+        if (tj <= i) A[i * CH_LD + tj] -= ci * col[tj];
+      } else if (Bm) {
+        Bm[i * CH_LD + tj] -= ci * xrow[tj];
+      }
+      if (u && tj == 31) u[i] -= ci * xrow[32];
+    }
+    if (ti == 0) {
+      if (tj > k && tj < m) A[tj * CH_LD + k] = col[tj];      // scaled column k of L
+      if (Bm && tj <= k) Bm[k * CH_LD + tj] = xrow[tj];        // row k of L^{-1}
+      if (tj == 0) { A[k * CH_LD + k] = d * rs; if (u) u[k] = xrow[32]; }
+    }
+  }
+  __syncthreads();
+}
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #ifdef FM_STAMPS
@@ -732,7 +773,8 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
   STAMP(6);
 
   const bool refgrp = B0.isref != 0;
-  double *R = stage, *Ri = stage + 32 * 32;
+  double *R = stage, *Ri = stage + 32 * CH_LD;              // row stride CH_LD
+  double *chcol = Ri + 32 * CH_LD, *chrow = chcol + 36, *chrs = chrow + 36;
   if (refgrp) {
     // ---- R = K_uu - V'V : wave -> tile (it, jt2)
     const int it = wid >> 1, jt2 = wid & 1;
@@ -749,9 +791,10 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
       for (int r = 0; r < 4; ++r) {
         const int i = it * 16 + l4 + 4 * r, j = jt2 * 16 + l15;
         if (i < M && j < M)
-          R[i * M + j] = (j <= i) ? cov_entry(cp, colx[i], coly[i], colmv[i], colx[j], coly[j], colmv[j]) - c[r] : 0.0;
+          R[i * CH_LD + j] = (j <= i) ? cov_entry(cp, colx[i], coly[i], colmv[i], colx[j], coly[j], colmv[j]) - c[r] : 0.0;
       }
     }
+    for (int idx = tid; idx < 32 * CH_LD; idx += NT) Ri[idx] = (idx / CH_LD == idx % CH_LD) ? 1.0 : 0.0;
   } else {
     if (tid < M) {
       const int j = tid;
@@ -777,11 +820,10 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
   for (int t = 0; t < J; ++t)
     for (int i = tid; i < s_am[t]; i += NT) wpa[s_ao[t] + i] = A.w[s_arow[t] + i];
   __syncthreads();
-  // ---- wave 0 factorises R in registers while waves 1..3 form hv = T w_pa
-  if (refgrp && wid == 0) {
-    wave_chol_inverse_32(R, M, Ri, &s_fail, lane);
-  } else {
-    const int w0 = refgrp ? wid - 1 : wid, nw = refgrp ? 3 : 4;
+  // ---- Ri = chol(R)^{-1}: workgroup-wide elimination in LDS; then hv = T w_pa
+  if (refgrp) block_chol_eliminate(R, Ri, nullptr, M, chcol, chrow, chrs, &s_fail);
+  {
+    const int w0 = wid, nw = 4;
     for (int j = w0; j < M; j += nw) {
       double a = 0.0;
       for (int k = lane; k < P; k += 64) a += KV[(size_t)k * ldKV + j] * wpa[k];
@@ -806,7 +848,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
       d4 c = (d4){0.0, 0.0, 0.0, 0.0};
       for (int st = 0; st < njs; ++st) {
         const int j = 4 * st + l4;
-        const double a = (i < M && j <= i) ? -Ri[i * M + j] : 0.0;
+        const double a = (i < M && j <= i) ? -Ri[i * CH_LD + j] : 0.0;
         const double b = KV[(size_t)krow * ldKV + j];
         c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
       }
@@ -818,14 +860,14 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     }
     for (int idx = tid; idx < M * M; idx += NT) {
       const int i = idx / M, j = idx - i * M;
-      pu[(size_t)i * ld + P + j] = Ri[idx];
+      pu[(size_t)i * ld + P + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
     }
     if (tid < M) {
       const int i = tid;
       double e = 0.0;
-      for (int j = 0; j <= i; ++j) e += Ri[i * M + j] * (colw[j] - hv[j]);
+      for (int j = 0; j <= i; ++j) e += Ri[i * CH_LD + j] * (colw[j] - hv[j]);
       wcore_part = e * e;
-      logdet_part = log(Ri[i * M + i]);
+      logdet_part = log(Ri[i * CH_LD + i]);
     }
     const double wcore = block_sum(wcore_part, s_red);
     const double logdet = block_sum(logdet_part, s_red);
@@ -1092,8 +1134,8 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   double *wv = Np + (size_t)Mr4 * ldN;           // maxP + 32 : ancestors' w, then the group's new w
   double *tv = wv + A.maxP + 32, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32;
   double *av = zc + 32;                          // MAXJ x 32
-  double *S = av + MAXJ * 32;                    // 32 x 32
-  int *colblk = (int *)(S + 32 * 32);
+  double *S = av + MAXJ * 32;                    // 32 x CH_LD
+  int *colblk = (int *)(S + 32 * CH_LD);
 
   int gidx = blockIdx.x;
   {
@@ -1197,7 +1239,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
         for (int c = 0; c < s_nch; ++c) a += A.acc[s_coff[c] + B0.acc_len + idx];
         if (i == j) a += tsq[i];
       }
-      S[idx] = a;
+      S[i * CH_LD + j] = a;
     }
     if (tid < M) {
       const int i = tid;
@@ -1206,19 +1248,14 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
       for (int c = 0; c < s_nch; ++c) a += A.acc[s_coff[c] + B0.acc_len + M * M + i];
       bv[i] = a + tsq[i] * yx[i];
     }
-    __syncthreads();
   }
   STAMP(3);
-  // Gram part of the message records, [ N_a' N_a ] + the children's records (spamtree_model.cpp:1158-1207): it does
-  // not depend on the draw, so in a reference group waves 1..3 form it while wave 0 factorises and solves
+  // Gram part of the message records, [ N_a' N_a ] + the children's records (spamtree_model.cpp:1158-1207); it does not
+  // depend on the draw and is skipped while it is still valid for the accepted theta
   double *rec = A.acc + B0.acc_off;
   const int nsteps = Mr4 >> 2;
-  if (refgrp && wid == 0) {
-    wave_chol_solve_32(S, M, bv, zc, wv + P, &s_fail, lane);
-    STAMP(7);
-  } else if (A.do_gram) {
-    const int w0 = refgrp ? wid - 1 : wid, nw = refgrp ? 3 : 4;
-    for (int u = w0; u < J * 4; u += nw) {
+  if (A.do_gram) {
+    for (int u = wid; u < J * 4; u += NT / 64) {
       const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
       const int ma = s_am[t], oa = s_ao[t];
       if (it * 16 >= ma || jt * 16 >= ma) continue;
@@ -1253,6 +1290,18 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
         const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
         if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
       }
+    }
+  }
+  if (refgrp) {
+    // w_u = L^{-T} (L^{-1} Smu + z): elimination carries the forward solve; the transposed solve walks the pivots back
+    block_chol_eliminate(S, nullptr, bv, M, av, av + 36, av + 72, &s_fail);
+    if (tid < M) bv[tid] += zc[tid];
+    const double *rsd = av + 72;
+    for (int k = M - 1; k >= 0; --k) {
+      __syncthreads();
+      const double wk = bv[k] * rsd[k];
+      if (tid < k) bv[tid] -= S[k * CH_LD + tid] * wk;
+      if (tid == 32) wv[P + k] = wk;
     }
   }
   __syncthreads();
@@ -1947,7 +1996,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         L.ldS = ldS; L.SRm = maxSub;
         size_t st = (size_t)L.SRm * L.ldS + 16;
         st = std::max(st, (size_t)2 * L.Pm4 + L.Pm4 / 2 + 2);   // prologue alias: ancestor x, y, outcome ids
-        st = std::max(st, (size_t)2 * 32 * 32);                   // epilogue alias: R, Ri
+        st = std::max(st, (size_t)2 * 32 * CH_LD + 3 * 36);       // epilogue alias: R, Ri (stride CH_LD), elimination scratch
         st = ((st + 1) & ~(size_t)1) + (size_t)L.ldS + 16;       // + the zero row at the end
         L.stage_dbl = (int)((st + 1) & ~(size_t)1);
         L.lds_fast = ((size_t)L.Pm4 * L.ldKV + 16 + L.stage_dbl + FM_VPART + 5 * 32) * 8 + 64 * 4 + 64;
@@ -1957,7 +2006,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         L.Mr4 = std::max(4, (maxM + 3) & ~3);
         L.ldN = (L.maxLd + 16 + 1) | 1;   // odd stride, room for the 16-wide tile overshoot
         L.ldN = std::max(L.ldN, L.maxP + 33);
-        const size_t dbl = (size_t)L.Mr4 * L.ldN + (size_t)L.maxP + 32 + 6 * 32 + (size_t)MAXJ * 32 + 32 * 32 + 16;
+        const size_t dbl = (size_t)L.Mr4 * L.ldN + (size_t)L.maxP + 32 + 6 * 32 + (size_t)MAXJ * 32 + 32 * CH_LD + 16;
         L.lds_sfast = dbl * 8 + 64 * 4 + 64;
         ok = L.lds_sfast <= h->lds_limit;
       }
