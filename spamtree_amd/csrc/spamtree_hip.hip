@@ -467,41 +467,77 @@ __device__ void wave_chol_solve_32(const double *S, int m, const double *b, cons
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Workgroup-wide (NT = 256 threads) right-looking Cholesky of an m x m (m <= 32) SPD matrix in LDS with the forward
-// elimination of a right-hand side carried along: thread (ti, tj) = (tid / 32, tid % 32) updates rows k+1+ti, +8, ...
-// of column tj.  Two barriers per pivot; the pivot reciprocal square roots end in rsd[].
-//   A  : m x m, row stride 33, lower triangle valid on entry; holds L (scaled columns) on exit
-//   Bm : identity on entry -> L^{-1} on exit (rows k finalised at pivot k), row stride 33; may be null
-//   u  : right-hand side -> L^{-1} u on exit; may be null
+// Workgroup-wide (NT = 256 threads) right-looking Cholesky of an m x m (m <= 32) SPD matrix with the forward
+// elimination of the identity (-> L^{-1}) and / or of a right-hand side (-> L^{-1} u) carried along.
+// Every thread keeps up to three matrix elements in REGISTERS for the whole factorisation (lower triangle of A, lower
+// triangle of B = I, the vector u, concatenated and dealt round-robin); per pivot only the pivot column of A, the
+// pivot row of B and the pivot entry of u are published through a double-buffered LDS vector: one barrier per pivot.
+//   A  : LDS, row stride CH_LD, lower triangle valid on entry; receives L on exit
+//   Bm : LDS, row stride CH_LD, receives L^{-1} (lower; the caller zeroes / ignores the upper part); may be null
+//   u  : LDS vector, receives L^{-1} u; may be null
+//   pub: LDS scratch, 2 x 3 x 36 doubles;  rsd: 1 / L[k][k]
 // ---------------------------------------------------------------------------------------------------------------
 #define CH_LD 33
-__device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, double *col, double *xrow, double *rsd, int *fail) {
-  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
+__device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, double *pub, double *rsd, int *fail) {
+  const int tid = threadIdx.x;
+  const int nA = m * (m + 1) / 2, nB = Bm ? nA : 0, nU = u ? m : 0, nE = nA + nB + nU;
+  __syncthreads();   // A / u were just written by other threads
+  // per element: rank-1 updates while klo <= k < khi, scaling (and publication) at k == ksc
+  //   A[i][j]: klo 0, khi j, ksc j (the diagonal entry equals the pivot, so d*rs = val*rs)   published at pa[i]
+  //   B[i][j]: klo j, khi i, ksc i                                                          published at pa[36 + j]
+  //   u[i]   : klo 0, khi i, ksc i                                                          published at pa[72]
+  int ty[3], ei[3], ej[3], o1[3], o2[3], klo[3], khi[3], ksc[3], opub[3];
+  double val[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int e = tid + NT * r;
+    ty[r] = 3; ei[r] = 0; ej[r] = 0; o1[r] = 0; o2[r] = 0; klo[r] = 0; khi[r] = 0; ksc[r] = -1; opub[r] = 0; val[r] = 0.0;
+    if (e < nE) {
+      int t = e < nA ? 0 : (e < nA + nB ? 1 : 2);
+      int f = e - (t == 0 ? 0 : (t == 1 ? nA : nA + nB));
+      int i, j;
+      if (t == 2) { i = f; j = 0; }
+      else {
+        i = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
+        while (i * (i + 1) / 2 > f) --i;
+        while ((i + 1) * (i + 2) / 2 <= f) ++i;
+        j = f - i * (i + 1) / 2;
+      }
+      ty[r] = t; ei[r] = i; ej[r] = j;
+      o1[r] = i;
+      o2[r] = t == 0 ? j : (t == 1 ? 36 + j : 72);   // second factor: column entry / row-k entry of B / u_k
+      klo[r] = t == 1 ? j : 0;
+      khi[r] = t == 0 ? j : i;
+      ksc[r] = t == 0 ? j : i;
+      opub[r] = t == 0 ? i : (t == 1 ? 36 + j : 72);
+      val[r] = t == 0 ? A[i * CH_LD + j] : (t == 1 ? (i == j ? 1.0 : 0.0) : u[i]);
+    }
+  }
   for (int k = 0; k < m; ++k) {
+    double *pa = pub + (k & 1) * 108;          // [0,36): column k of A   [36,72): row k of B   [72]: u_k   (unscaled)
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (k == ksc[r]) pa[opub[r]] = val[r];
     __syncthreads();
-    const double d = A[k * CH_LD + k];
+    const double d = pa[k];
+    double x1[3], x2[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { x1[r] = pa[o1[r]]; x2[r] = pa[o2[r]]; }
     if (!(d > 0.0) && tid == 0) *fail = 1;
     const double rs = rsqrt(d);
-    if (tid < m) {
-      if (tid > k) col[tid] = A[tid * CH_LD + k] * rs;
-      else if (Bm) xrow[tid] = Bm[k * CH_LD + tid] * rs;
+    if (tid == 0) rsd[k] = rs;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double vu = val[r] - (x1[r] * rs) * (x2[r] * rs);
+      const double vs = val[r] * rs;
+      val[r] = (k >= klo[r] && k < khi[r]) ? vu : ((k == ksc[r]) ? vs : val[r]);
     }
-    if (tid == 32) { rsd[k] = rs; if (u) xrow[32] = u[k] * rs; }
-    __syncthreads();
-    for (int i = k + 1 + ti; i < m; i += 8) {
-      const double ci = col[i];
-      if (tj > k) {
-        if (tj <= i) A[i * CH_LD + tj] -= ci * col[tj];
-      } else if (Bm) {
-        Bm[i * CH_LD + tj] -= ci * xrow[tj];
-      }
-      if (u && tj == 31) u[i] -= ci * xrow[32];
-    }
-    if (ti == 0) {
-      if (tj > k && tj < m) A[tj * CH_LD + k] = col[tj];      // scaled column k of L
-      if (Bm && tj <= k) Bm[k * CH_LD + tj] = xrow[tj];        // row k of L^{-1}
-      if (tj == 0) { A[k * CH_LD + k] = d * rs; if (u) u[k] = xrow[32]; }
-    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (ty[r] == 0) A[ei[r] * CH_LD + ej[r]] = val[r];
+    if (ty[r] == 1) Bm[ei[r] * CH_LD + ej[r]] = val[r];
+    if (ty[r] == 2) u[ei[r]] = val[r];
   }
   __syncthreads();
 }
@@ -774,7 +810,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 
   const bool refgrp = B0.isref != 0;
   double *R = stage, *Ri = stage + 32 * CH_LD;              // row stride CH_LD
-  double *chcol = Ri + 32 * CH_LD, *chrow = chcol + 36, *chrs = chrow + 36;
+  double *chcol = Ri + 32 * CH_LD, *chrs = chcol + 216;       // elimination scratch: 2 x 3 x 36 published entries, pivots
   if (refgrp) {
     // ---- R = K_uu - V'V : wave -> tile (it, jt2)
     const int it = wid >> 1, jt2 = wid & 1;
@@ -821,7 +857,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     for (int i = tid; i < s_am[t]; i += NT) wpa[s_ao[t] + i] = A.w[s_arow[t] + i];
   __syncthreads();
   // ---- Ri = chol(R)^{-1}: workgroup-wide elimination in LDS; then hv = T w_pa
-  if (refgrp) block_chol_eliminate(R, Ri, nullptr, M, chcol, chrow, chrs, &s_fail);
+  if (refgrp) block_chol_eliminate(R, Ri, nullptr, M, chcol, chrs, &s_fail);
   {
     const int w0 = wid, nw = 4;
     for (int j = w0; j < M; j += nw) {
@@ -1294,9 +1330,9 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   }
   if (refgrp) {
     // w_u = L^{-T} (L^{-1} Smu + z): elimination carries the forward solve; the transposed solve walks the pivots back
-    block_chol_eliminate(S, nullptr, bv, M, av, av + 36, av + 72, &s_fail);
+    block_chol_eliminate(S, nullptr, bv, M, av, av + 216, &s_fail);
     if (tid < M) bv[tid] += zc[tid];
-    const double *rsd = av + 72;
+    const double *rsd = av + 216;
     for (int k = M - 1; k >= 0; --k) {
       __syncthreads();
       const double wk = bv[k] * rsd[k];
@@ -1996,7 +2032,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         L.ldS = ldS; L.SRm = maxSub;
         size_t st = (size_t)L.SRm * L.ldS + 16;
         st = std::max(st, (size_t)2 * L.Pm4 + L.Pm4 / 2 + 2);   // prologue alias: ancestor x, y, outcome ids
-        st = std::max(st, (size_t)2 * 32 * CH_LD + 3 * 36);       // epilogue alias: R, Ri (stride CH_LD), elimination scratch
+        st = std::max(st, (size_t)2 * 32 * CH_LD + 216 + 36);     // epilogue alias: R, Ri (stride CH_LD), elimination scratch
         st = ((st + 1) & ~(size_t)1) + (size_t)L.ldS + 16;       // + the zero row at the end
         L.stage_dbl = (int)((st + 1) & ~(size_t)1);
         L.lds_fast = ((size_t)L.Pm4 * L.ldKV + 16 + L.stage_dbl + FM_VPART + 5 * 32) * 8 + 64 * 4 + 64;
