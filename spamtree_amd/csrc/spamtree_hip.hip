@@ -478,6 +478,7 @@ __device__ void wave_chol_solve_32(const double *S, int m, const double *b, cons
 //   pub: LDS scratch, 2 x 3 x 36 doubles;  rsd: 1 / L[k][k]
 // ---------------------------------------------------------------------------------------------------------------
 #define CH_LD 33
+#define CH_EPT 5
 __device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, double *pub, double *rsd, int *fail) {
   const int tid = threadIdx.x;
   const int nA = m * (m + 1) / 2, nB = Bm ? nA : 0, nU = u ? m : 0, nE = nA + nB + nU;
@@ -486,10 +487,11 @@ __device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, do
   //   A[i][j]: klo 0, khi j, ksc j (the diagonal entry equals the pivot, so d*rs = val*rs)   published at pa[i]
   //   B[i][j]: klo j, khi i, ksc i                                                          published at pa[36 + j]
   //   u[i]   : klo 0, khi i, ksc i                                                          published at pa[72]
-  int ty[3], ei[3], ej[3], o1[3], o2[3], klo[3], khi[3], ksc[3], opub[3];
-  double val[3];
+  const int ept = (nE + NT - 1) / NT;   // elements per thread: 3 for m <= 26, up to 5 for m = 32 (uniform)
+  int ty[CH_EPT], ei[CH_EPT], ej[CH_EPT], o1[CH_EPT], o2[CH_EPT], klo[CH_EPT], khi[CH_EPT], ksc[CH_EPT], opub[CH_EPT];
+  double val[CH_EPT];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < CH_EPT; ++r) {
     const int e = tid + NT * r;
     ty[r] = 3; ei[r] = 0; ej[r] = 0; o1[r] = 0; o2[r] = 0; klo[r] = 0; khi[r] = 0; ksc[r] = -1; opub[r] = 0; val[r] = 0.0;
     if (e < nE) {
@@ -516,25 +518,25 @@ __device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, do
   for (int k = 0; k < m; ++k) {
     double *pa = pub + (k & 1) * 108;          // [0,36): column k of A   [36,72): row k of B   [72]: u_k   (unscaled)
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-      if (k == ksc[r]) pa[opub[r]] = val[r];
+    for (int r = 0; r < CH_EPT; ++r)
+      if (r < ept && k == ksc[r]) pa[opub[r]] = val[r];
     __syncthreads();
     const double d = pa[k];
-    double x1[3], x2[3];
+    double x1[CH_EPT], x2[CH_EPT];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { x1[r] = pa[o1[r]]; x2[r] = pa[o2[r]]; }
+    for (int r = 0; r < CH_EPT; ++r) if (r < ept) { x1[r] = pa[o1[r]]; x2[r] = pa[o2[r]]; }
     if (!(d > 0.0) && tid == 0) *fail = 1;
     const double rs = rsqrt(d);
     if (tid == 0) rsd[k] = rs;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < CH_EPT; ++r) if (r < ept) {
       const double vu = val[r] - (x1[r] * rs) * (x2[r] * rs);
       const double vs = val[r] * rs;
       val[r] = (k >= klo[r] && k < khi[r]) ? vu : ((k == ksc[r]) ? vs : val[r]);
     }
   }
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < CH_EPT; ++r) {
     if (ty[r] == 0) A[ei[r] * CH_LD + ej[r]] = val[r];
     if (ty[r] == 1) Bm[ei[r] * CH_LD + ej[r]] = val[r];
     if (ty[r] == 2) u[ei[r]] = val[r];

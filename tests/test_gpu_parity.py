@@ -39,6 +39,13 @@ CASES = [
     dict(side=16, q=2, missing=0.0),
     dict(side=14, q=3, missing=0.2),
     dict(side=25, q=1, missing=0.0, last_not_reference=False),
+    # q = 3 with cell_size = 9 (config #5's shape): 27-row blocks -> the MFMA kernels evaluate the Apanasovich-Genton form
+    dict(side=18, q=3, missing=0.25, cell_size=9),
+    dict(side=20, q=2, missing=0.0, cell_size=16),
+    # unusual trees: 3 x 2 branching, small cells, a finite depth with a nearest-neighbour leftover level
+    dict(side=30, q=1, missing=0.1, cell_size=9, K=(3, 2)),
+    dict(side=30, q=1, missing=0.0, tree_depth=2),
+    dict(side=36, q=1, missing=0.05, cell_size=16, random_coords=True),
 ]
 
 
