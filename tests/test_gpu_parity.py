@@ -216,3 +216,30 @@ def test_running_posterior_means():
     assert hm.lib.st_summary_get(hm.h, _dp(wm), _dp(ym), C.byref(cnt)) == 0 and cnt.value == 4
     assert np.abs(wm - np.mean(ws, axis=0)).max() < 1e-13 and np.abs(ym - np.mean(ys, axis=0)).max() < 1e-13
     hm.close()
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[6], CASES[8]])
+def test_second_generation_factor_kernel(case, monkeypatch):
+    """k_factor_mfma2 (SPAMTREE_FACTOR_KERNEL=2, read at st_create) gives the same factors as the oracle."""
+    monkeypatch.setenv("SPAMTREE_FACTOR_KERNEL", "2")
+    pb = make_problem(seed=31, **case)
+    rng = np.random.default_rng(6)
+    w0 = rng.standard_normal(pb["n"])
+    om = oracle_model(pb, w=w0, tausq=0.2)
+    hm = hip_model(pb, w=w0, tausq=0.2)
+    assert om.get_loglik_comps_w(om.param_data) and hm.get_loglik_comps_w(0)
+    assert abs(hm.loglik_w[0] - om.param_data.loglik_w) <= REL * abs(om.param_data.loglik_w)
+    ld, ll = hm.comps(0)
+    assert relerr(ld, om.param_data.logdetCi_comps) <= REL and relerr(ll, om.param_data.loglik_w_comps) <= REL
+    for u in range(om.n_blocks):
+        if om.block_ct_obs[u] == 0:
+            continue
+        H, Ri = hm.block(0, u)
+        if om.parents[u].size:
+            assert relerr(H, om.param_data.w_cond_mean_K[u]) <= 1e-8, u
+        ref_ri = om.param_data.Rcc_invchol[u] if om.block_is_reference[u] else om.param_data.ccholprecdiag[u]
+        assert relerr(Ri, ref_ri) <= REL, u
+    z = rng.standard_normal(pb["n"])
+    om.gibbs_sample_w(z); hm.deal_with_w(z)
+    assert relerr(hm.get_w()[om.na_ix_all], om.w[om.na_ix_all]) <= REL
+    hm.close()
