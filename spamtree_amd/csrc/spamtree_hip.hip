@@ -1866,18 +1866,33 @@ __global__ __launch_bounds__(NT) void k_loglik(LoglikArgs A) {
   }
 }
 
-// fixed-shape deterministic sum of two arrays: out[0] = sum a, out[1] = sum b  (one workgroup)
-__global__ __launch_bounds__(1024) void k_sum2(const double *a, const double *b, int n, double *out) {
-  __shared__ double sa[1024], sb[1024];
+// fixed-shape deterministic sums of two arrays: out[0] = sum a, out[1] = sum b.  Stage 1: SUM2_WG workgroups, each a
+// contiguous chunk (thread-strided partial sums, LDS tree); stage 2: one wave adds the SUM2_WG partials in order.
+#define SUM2_WG 64
+__global__ __launch_bounds__(NT) void k_sum2_partial(const double *a, const double *b, int n, double *partial) {
+  __shared__ double sa[NT], sb[NT];
+  const int chunk = (n + SUM2_WG - 1) / SUM2_WG;
+  const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
   double xa = 0.0, xb = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) { xa += a[i]; xb += b[i]; }
+  for (int i = lo + threadIdx.x; i < hi; i += NT) { xa += a[i]; xb += b[i]; }
   sa[threadIdx.x] = xa; sb[threadIdx.x] = xb;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+  for (int s2 = NT / 2; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) { sa[threadIdx.x] += sa[threadIdx.x + s2]; sb[threadIdx.x] += sb[threadIdx.x + s2]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sa[0]; partial[2 * blockIdx.x + 1] = sb[0]; }
+}
+__global__ void k_sum2_final(const double *partial, double *out) {
+  if (threadIdx.x < 2) {
+    double s2 = 0.0;
+    for (int g = 0; g < SUM2_WG; ++g) s2 += partial[2 * g + threadIdx.x];
+    out[threadIdx.x] = s2;
+  }
+}
+static void launch_sum2(hipStream_t st, const double *a, const double *b, int n, double *partial, double *out) {
+  hipLaunchKernelGGL(k_sum2_partial, dim3(SUM2_WG), dim3(NT), 0, st, a, b, n, partial);
+  hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(64), 0, st, partial, out);
 }
 
 // XB = X * Bcoeff[:, mv]   (spamtree_model.cpp:127, 1382); X is column-major n x p in device row order
@@ -2022,6 +2037,7 @@ struct st_handle_s {
   DevBuf<double> d_sum_w, d_sum_yhat;         // running sums over saved iterations (st_summary_*)
   long long n_summary = 0;
   int factor_gen = 1;
+  bool stats_valid = false;                   // d_stats matches the current w and XB
   bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
   bool cache_gram = true;
   ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
@@ -2613,7 +2629,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   }
   CCHK(h->d_acc.alloc(std::max<size_t>(h->acc_total, 1)));
   CCHK(hipMemset(h->d_acc.p, 0, std::max<size_t>(h->acc_total, 1) * sizeof(double)));
-  CCHK(h->d_scalars.alloc(8));
+  CCHK(h->d_scalars.alloc(8 + 2 * SUM2_WG));
   CCHK(h->d_err.alloc(2));
   CCHK(h->d_partial.alloc((size_t)STATS_WG * (pb->p * pb->q + pb->q)));
   CCHK(h->d_stats.alloc((size_t)pb->p * pb->q + pb->q));
@@ -2679,6 +2695,7 @@ static int download_rows(st_handle h, const double *src, double *dst) {
 
 extern "C" int st_set_w(st_handle h, const double *w) {
   if (!h || !w) return ST_ERR_USAGE;
+  h->stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   return upload_rows(h, w, h->d_w.p);
 }
@@ -2694,6 +2711,7 @@ extern "C" int st_get_xb(st_handle h, double *xb) {
 }
 extern "C" int st_set_beta(st_handle h, const double *Bcoeff) {
   if (!h || !Bcoeff) return ST_ERR_USAGE;
+  h->stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   HCHK(h, hipMemcpyAsync(h->d_B.p, Bcoeff, (size_t)h->p * h->q * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
@@ -2778,7 +2796,7 @@ static void launch_factor(st_handle h, const LevelInfo &L, FactorArgs &A, const 
 static int reduce_loglik(st_handle h, int phys, double *loglik) {
   {
     ProfScope ps(h, 3);
-    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(1024), 0, h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p);
+    launch_sum2(h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p + 8, h->d_scalars.p);
   }
   HCHK(h, hipGetLastError());
   double s[2];
@@ -2891,7 +2909,7 @@ extern "C" int st_mg_finish(st_handle h, double *loglik) {
   const int nb = (int)h->n_blocks;
   {
     ProfScope ps(h, 3);
-    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(1024), 0, h->stream, h->d_comm.p, h->d_comm.p + nb, nb, h->d_scalars.p);
+    launch_sum2(h->stream, h->d_comm.p, h->d_comm.p + nb, nb, h->d_scalars.p + 8, h->d_scalars.p);
   }
   HCHK(h, hipGetLastError());
   double s2[2], errw[64];
@@ -3009,6 +3027,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
 // that an all-reduce(sum) over st_mg_top_region() completes them
 extern "C" int st_sample_w_local(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
   if (!h) return ST_ERR_USAGE;
+  h->stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   int rc = gen_or_upload_z(h, z, seed, iter, 0u, h->d_z.p);
   if (rc) return rc;
@@ -3028,6 +3047,7 @@ extern "C" int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len) {
 }
 extern "C" int st_sample_w_top(st_handle h) {   // the replicated levels above the cut
   if (!h) return ST_ERR_USAGE;
+  h->stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   const int rc = sample_launch(h, std::min(h->cut, h->n_actual_groups), 0);
   if (rc == ST_OK) h->gram_valid = true;   // every record now carries the Gram sums of the accepted theta
@@ -3046,6 +3066,7 @@ extern "C" int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len) {
 }
 extern "C" int st_mg_unpack_w(st_handle h) {
   if (!h) return ST_ERR_USAGE;
+  h->stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   double errw[64];
   HCHK(h, hipMemcpyAsync(h->d_w.p, h->d_tmp_n.p, (size_t)h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -3121,6 +3142,7 @@ extern "C" int st_predict(st_handle h, int theta_changed) {
   (void)theta_changed;  // H of a prediction block is rebuilt from the ancestor chain every call: same values as the cache
   if (!h) return ST_ERR_USAGE;
   if (h->pred_list.empty()) return ST_OK;
+  h->stats_valid = false;
   if (!h->z_valid) { h->err = "st_predict needs the normals of a preceding st_sample_w (spamtree_model.cpp:1325)"; return ST_ERR_USAGE; }
   if (h->theta[0].empty()) { h->err = "st_predict before st_factor(slot 0)"; return ST_ERR_USAGE; }
   HCHK(h, hipSetDevice(h->device));
@@ -3146,6 +3168,7 @@ extern "C" int st_predict(st_handle h, int theta_changed) {
 
 static int run_stats(st_handle h) {
   const int nq = h->p * h->q + h->q;
+  if (h->stats_valid) return ST_OK;   // w and XB unchanged since the last reduction: both statistics are still current
   {
     ProfScope ps(h, 4);
     hipLaunchKernelGGL(k_stats, dim3(STATS_WG), dim3(NT), 0, h->stream, h->d_X.p, h->d_y.p, h->d_w.p, h->d_xb.p, h->d_mv.p, h->d_obs.p,
@@ -3153,6 +3176,7 @@ static int run_stats(st_handle h) {
     hipLaunchKernelGGL(k_stats_final, dim3(nq), dim3(NT), 0, h->stream, h->d_partial.p, STATS_WG, nq, h->d_stats.p);
   }
   HCHK(h, hipGetLastError());
+  h->stats_valid = true;
   return ST_OK;
 }
 extern "C" int st_beta_stats(st_handle h, double *xty) {
