@@ -1,0 +1,604 @@
+// Phase A, third generation ("quads").  Included by spamtree_hip.hip (needs Blk, Grp, CovPar, cov_entry, d4, CH_LD).
+//
+// A workgroup factorises up to NU "units" at once.  A unit is what k_factor_mfma calls a column group: one reference
+// block, or up to 32 columns of sibling non-reference blocks.  The units of a quad share their ancestor chain, except
+// possibly for the last ancestor ("private" ancestor: leaf groups whose parents are siblings).  The shared chain's
+// inverse-Cholesky panels are staged through LDS ONCE for all units, in 16-row sub-panels, double-buffered, one barrier
+// per sub-panel; per sub-panel every wave has 4x the matrix work of k_factor_mfma between barriers and nothing is
+// exchanged between the waves of the main loop:
+//   * wave (u, jt) owns 16 columns of unit u over the WHOLE chain: its K_{pa,u} B operands live in registers (kx),
+//     evaluated once straight from the coordinates; so do its T = H_u accumulators (tacc, tiles [column][chain]);
+//   * V_sub = Linv_sub K (A from LDS, B = kx);  T += V_sub' Linv_sub (the V tile in C layout is the A operand, B from
+//     LDS);  the Schur complement K_uu - V'V is accumulated on the fly (reference units: MFMA on the V tiles, the
+//     off-diagonal tile uses the partner wave's V tile of the previous sub-panel through LDS; leaf units: diagonal only);
+//   * epilogue: NU Cholesky eliminations side by side (team = the unit's two waves, one barrier per pivot for all),
+//     N = -Ri T on the matrix cores with the T tiles as B operands (half of them swapped between the two waves so that
+//     each wave holds all columns for its chain tiles), outputs straight from registers.
+// Chain length P <= 4 * NKX, NKT = ceil(P / 16) T tiles.  Results equal k_factor_mfma's up to rounding.
+#pragma once
+
+struct Quad {
+  int g0, nu;   // units = column groups g0 .. g0+nu-1 of the launch's group list
+  int Jc, Pc;   // shared chain: the first Jc ancestors of every unit (Pc rows); a unit has Jc or Jc + 1 ancestors
+};
+
+struct QuadArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const Grp *grps;
+  const Quad *quads;
+  int nquad;
+  const double *cx, *cy;
+  const int *mv;
+  const double *w;
+  double *panels;
+  double *logdet_c, *loglik_c;
+  int *errflag;
+  int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
+};
+
+#define TCH_EPT 9
+// Team version of block_chol_eliminate: the workgroup is split into teams of 128 threads, each team eliminates its own
+// m x m matrix ([A | I] -> [L | L^{-1}]); all teams run the same pivot loop (mmax = largest m, uniform) and share its
+// barrier.  A: LDS, row stride CH_LD, lower triangle valid; Bm receives L^{-1} (lower); pub: 216 doubles per team.
+__device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
+  const int nA = m * (m + 1) / 2, nE = 2 * nA;
+  lds_barrier();
+  int o1[TCH_EPT], o2[TCH_EPT], klo[TCH_EPT], khi[TCH_EPT], opub[TCH_EPT], eoff[TCH_EPT];
+  double val[TCH_EPT];
+#pragma unroll
+  for (int r = 0; r < TCH_EPT; ++r) {
+    const int e = ttid + 128 * r;
+    o1[r] = 0; o2[r] = 0; klo[r] = 0; khi[r] = -1; opub[r] = 0; eoff[r] = -1; val[r] = 0.0;
+    if (e < nE) {
+      const int t = e < nA ? 0 : 1;
+      const int f = e - t * nA;
+      int i = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > f) --i;
+      while ((i + 1) * (i + 2) / 2 <= f) ++i;
+      const int j = f - i * (i + 1) / 2;
+      o1[r] = i;
+      o2[r] = t == 0 ? j : 36 + j;
+      klo[r] = t == 1 ? j : 0;
+      khi[r] = t == 0 ? j : i;        // rank-1 updates while klo <= k < khi, scaling and publication at k == khi
+      opub[r] = t == 0 ? i : 36 + j;
+      eoff[r] = (t == 0 ? 0 : 1) * 65536 + i * CH_LD + j;
+      val[r] = t == 0 ? Am[i * CH_LD + j] : (i == j ? 1.0 : 0.0);
+    }
+  }
+  for (int k = 0; k < mmax; ++k) {
+    double *pa = pub + (k & 1) * 108;   // [0,36): column k of A   [36,72): row k of B   (unscaled)
+#pragma unroll
+    for (int r = 0; r < TCH_EPT; ++r)
+      if (k == khi[r]) pa[opub[r]] = val[r];
+    lds_barrier();
+    if (k < m) {
+      const double d = pa[k];
+      double x1[TCH_EPT], x2[TCH_EPT];
+#pragma unroll
+      for (int r = 0; r < TCH_EPT; ++r) { x1[r] = pa[o1[r]]; x2[r] = pa[o2[r]]; }
+      if (!(d > 0.0) && ttid == 0) *fail = 1;
+      const double rs = rsqrt(d);
+#pragma unroll
+      for (int r = 0; r < TCH_EPT; ++r) {
+        const double vu = val[r] - (x1[r] * rs) * (x2[r] * rs);
+        const double vs = val[r] * rs;
+        val[r] = (k >= klo[r] && k < khi[r]) ? vu : ((k == khi[r]) ? vs : val[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TCH_EPT; ++r) {
+    if (eoff[r] >= 65536) Bm[eoff[r] - 65536] = val[r];
+    else if (eoff[r] >= 0) Am[eoff[r]] = val[r];
+  }
+  lds_barrier();
+}
+
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+
+template <int NU, int NKX, int NKT, bool ISREF>
+__global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar cp) {
+  constexpr int NTQ = 128 * NU, NW = 2 * NU, NC = 32 * NU, RPW = 16 / NW;
+  constexpr int PMAX = 4 * NKX, KH = (NKX + 1) / 2;   // K-steps evaluated per pass through the arena
+  static_assert(NKT * 16 >= PMAX, "T tiles must cover the chain");
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
+  __shared__ int s_uM[NU], s_uP[NU], s_ublk0[NU], s_unblk[NU], s_uref[NU], s_uJ[NU], s_pm[NU], s_fail[NU], s_level;
+  __shared__ long long s_urow0[NU], s_prow[NU], s_ppan[NU];
+  __shared__ long long s_bpan[NU][32], s_brow[NU][32];
+  __shared__ int s_bld[NU][32];
+  __shared__ double s_colx[NU][32], s_coly[NU][32], s_colw[NU][32], s_hv[NU][32], s_rd[NU][32], s_px[NU][32], s_py[NU][32], s_pw[NU][32];
+  __shared__ double s_e2[NU][32], s_lg[NU][32];
+  __shared__ int s_colmv[NU][32], s_colblk[NU][32], s_pmv[NU][32];
+  __shared__ double s_sx[PMAX], s_sy[PMAX], s_wpa[PMAX];
+  __shared__ int s_smv[PMAX];
+
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, ttid = tid & 127;
+  const int wid = RFL(tid >> 6), u = wid >> 1, jt = wid & 1;
+  const int ldS = A.ldS;
+  double *arena = lds;
+  double *zrow = arena + (size_t)NU * 16 * ldS;   // a row of zeros
+  double *xch = zrow + ldS;                       // V tiles of the jt = 1 waves: [2][NU][256]
+
+  STAMP_DECL
+  int qidx = blockIdx.x;
+  {
+    const int per = A.nquad >> 3;   // one contiguous run of quads per XCD (private L2): neighbours share chain panels
+    if (qidx < per * 8) qidx = (qidx & 7) * per + (qidx >> 3);
+  }
+  const Quad Q = A.quads[qidx];
+  const int Jc = Q.Jc, Pc = Q.Pc, nu = Q.nu;
+
+  // ---- topology of the quad
+  if (tid < NU) {
+    int M = 0, P = 0, blk0 = 0, nblk = 0, isref = 0, J = 0, pm = 0;
+    long long row0 = 0, prow = 0, ppan = 0;
+    if (tid < nu) {
+      const Grp G = A.grps[Q.g0 + tid];
+      const Blk B0 = A.blks[G.blk0];
+      M = G.M; P = G.P; blk0 = G.blk0; nblk = G.nblk; row0 = G.row0; isref = B0.isref; J = B0.nanc;
+      if (tid == 0) s_level = B0.level;
+      if (B0.nanc > Jc) {
+        const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + Jc]];
+        pm = Ba.m; prow = Ba.row0; ppan = Ba.panel_off;
+      }
+    }
+    s_uM[tid] = M; s_uP[tid] = P; s_ublk0[tid] = blk0; s_unblk[tid] = nblk; s_uref[tid] = isref; s_uJ[tid] = J;
+    s_pm[tid] = pm; s_urow0[tid] = row0; s_prow[tid] = prow; s_ppan[tid] = ppan; s_fail[tid] = 0;
+  }
+  if (tid >= 64 && tid < 64 + Jc) {
+    const int t = tid - 64;
+    const Blk B0 = A.blks[A.grps[Q.g0].blk0];
+    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + t]];
+    s_am[t] = Ba.m; s_arow[t] = Ba.row0; s_apan[t] = Ba.panel_off;
+  }
+  for (int k = tid; k < ldS; k += NTQ) zrow[k] = 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int t = 0; t < Jc; ++t) { s_ao[t] = o; o += s_am[t]; }
+    s_ao[Jc] = o;
+  }
+  for (int e = tid; e < NU * 32; e += NTQ) {
+    const int uu = e >> 5, b = e & 31;
+    if (b < s_unblk[uu]) {
+      const Blk Bb = A.blks[s_ublk0[uu] + b];
+      s_bpan[uu][b] = Bb.panel_off; s_brow[uu][b] = Bb.row0; s_bld[uu][b] = Bb.ld;
+    }
+  }
+  __syncthreads();
+  const int Mu = RFL(s_uM[u]), Pu = RFL(s_uP[u]), pmu = RFL(s_pm[u]);
+  constexpr bool isref = ISREF;   // a level is all reference blocks or all leaf groups (host)
+  const bool wact = jt * 16 < Mu;   // this wave owns at least one column
+  const bool two = Mu > 16;
+  int Mmax = 0, pmmax = 0;
+#pragma unroll
+  for (int i = 0; i < NU; ++i) { Mmax = max(Mmax, s_uM[i]); pmmax = max(pmmax, s_pm[i]); }
+  Mmax = RFL(Mmax); pmmax = RFL(pmmax);
+  constexpr bool anyref = ISREF;
+
+  // ---- coordinates and w of the shared chain, of the private ancestors, of the units' columns
+  for (int k = tid; k < Pc; k += NTQ) {
+    int t = 0;
+    while (t + 1 < Jc && k >= s_ao[t + 1]) ++t;
+    const long long r = s_arow[t] + (k - s_ao[t]);
+    s_sx[k] = A.cx[r]; s_sy[k] = A.cy[r]; s_smv[k] = A.mv[r]; s_wpa[k] = A.w[r];
+  }
+  for (int e = tid; e < NU * 32; e += NTQ) {
+    const int uu = e >> 5, i = e & 31;
+    double x = 0.0, y = 0.0, ww = 0.0; int v = 0;
+    if (i < s_pm[uu]) { const long long r = s_prow[uu] + i; x = A.cx[r]; y = A.cy[r]; ww = A.w[r]; v = A.mv[r]; }
+    s_px[uu][i] = x; s_py[uu][i] = y; s_pw[uu][i] = ww; s_pmv[uu][i] = v;
+    x = 0.0; y = 0.0; ww = 0.0; v = 0;
+    int bi = 0;
+    if (i < s_uM[uu]) {
+      const long long r = s_urow0[uu] + i;
+      x = A.cx[r]; y = A.cy[r]; ww = A.w[r]; v = A.mv[r];
+      while (bi + 1 < s_unblk[uu] && r >= s_brow[uu][bi + 1]) ++bi;
+    }
+    s_colx[uu][i] = x; s_coly[uu][i] = y; s_colw[uu][i] = ww; s_colmv[uu][i] = v; s_colblk[uu][i] = bi;
+  }
+  __syncthreads();
+
+  STAMP(0);
+  // ---- private (last) ancestors, first sub-panel: the loads start now and travel while K is evaluated
+  const int p_sr0 = pmu > 16 ? (pmu + 1) >> 1 : pmu;   // rows of the first private sub-panel
+  const int p_Kb = Pc + pmu;
+  double ptmp[32];
+  if (pmmax > 0) {
+    const double *src = A.panels + s_ppan[u] + lane;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = jt + 2 * rr;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        ptmp[rr * 4 + c] = (row < p_sr0 && lane + 64 * c < p_Kb) ? src[(size_t)row * p_Kb + 64 * c] : 0.0;
+    }
+  }
+
+  // ---- K_{pa,u}: every lane evaluates the B operands of its own K-steps, kx[st] = K[4 st + l4][column jt*16 + l15 of
+  // unit u], in a rolled loop (one covariance body per pass) through lane-private LDS slots, then picks them up with
+  // static register indices.  No barrier: nobody else touches the slots.
+  double kx[NKX];
+  {
+    const int jc = jt * 16 + l15;
+    const bool cok = jc < Mu;
+    const double mx = s_colx[u][jc], my = s_coly[u][jc];
+    const int mvj = s_colmv[u][jc];
+    double *kb = arena + (size_t)wid * (KH * 64) + lane;   // [KH][64] per wave; NW * KH * 64 <= NU * 16 * ldS (host)
+#pragma unroll
+    for (int hpass = 0; hpass < 2; ++hpass) {
+      const int st0 = hpass * KH;
+      if (4 * st0 < Pu) {
+#pragma unroll 1
+        for (int i = 0; i < KH; ++i) {
+          const int k = 4 * (st0 + i) + l4;
+          double v = 0.0;
+          if (cok && k < Pu) {
+            double ax, ay; int av;
+            if (k < Pc) { ax = s_sx[k]; ay = s_sy[k]; av = s_smv[k]; }
+            else { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
+            v = cov_entry(cp, ax, ay, av, mx, my, mvj);
+          }
+          kb[i * 64] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < KH; ++i)
+          if (st0 + i < NKX) kx[st0 + i] = kb[i * 64];
+      } else {
+#pragma unroll
+        for (int i = 0; i < KH; ++i)
+          if (st0 + i < NKX) kx[st0 + i] = 0.0;
+      }
+    }
+  }
+  lds_barrier();   // the arena is handed over to the staging
+  STAMP(1);
+  d4 tacc[NKT];
+#pragma unroll
+  for (int n = 0; n < NKT; ++n) tacc[n] = (d4){0.0, 0.0, 0.0, 0.0};
+  d4 rown = (d4){0.0, 0.0, 0.0, 0.0}, rcross = rown, vprev = rown;   // Schur tiles (jt, jt) and (1, 0); previous V tile
+  double dacc = 0.0;                                               // leaf units: sum_k V[k][column l15]^2 (this lane's rows)
+  int par = 0;
+  bool have_prev = false;
+
+  // one sub-panel (sr <= 16 rows of Linv, row length Kb, staged at stg with stride ldS, columns [Kb, Kb+24) zero)
+  auto compute = [&](const double *stg, int sr, int Kb) {
+    if (isref && jt == 0 && two && have_prev) {
+      const double *xp = xch + ((par ^ 1) * NU + u) * 256 + lane;
+      const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
+      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, vprev[0], rcross, 0, 0, 0);
+      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, vprev[1], rcross, 0, 0, 0);
+      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, vprev[2], rcross, 0, 0, 0);
+      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, vprev[3], rcross, 0, 0, 0);
+    }
+    // V = Linv_sub[:, 0:Kb] K[0:Kb, own columns]
+    const int ns = (Kb + 3) >> 2;
+    d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+    {
+      const double *ap = ((l15 < sr) ? stg + (size_t)l15 * ldS : zrow) + l4;
+#pragma unroll
+      for (int c = 0; c < (NKX + 3) / 4; ++c) {
+        if (4 * c < ns) {
+          double a[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[i] = ap[4 * (4 * c + i)];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (4 * c + i < NKX) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], kx[4 * c + i], p, 0, 0, 0);
+        }
+      }
+    }
+    // T[column][chain k] += V_sub' Linv_sub: A = V tile (C layout read as A: contraction over the sub-panel rows)
+    {
+      const int nst = (sr + 3) >> 2;
+      const double *b0 = ((l4 < sr) ? stg + (size_t)l4 * ldS : zrow) + l15;
+      const double *b1 = ((4 + l4 < sr) ? stg + (size_t)(4 + l4) * ldS : zrow) + l15;
+      const double *b2 = ((8 + l4 < sr) ? stg + (size_t)(8 + l4) * ldS : zrow) + l15;
+      const double *b3 = ((12 + l4 < sr) ? stg + (size_t)(12 + l4) * ldS : zrow) + l15;
+#pragma unroll
+      for (int n = 0; n < NKT; ++n) {
+        if (n * 16 < Kb) {
+          const double x0 = b0[16 * n], x1 = b1[16 * n], x2 = b2[16 * n], x3 = b3[16 * n];
+          tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], x0, tacc[n], 0, 0, 0);
+          if (nst > 1) tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[1], x1, tacc[n], 0, 0, 0);
+          if (nst > 2) tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[2], x2, tacc[n], 0, 0, 0);
+          if (nst > 3) tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[3], x3, tacc[n], 0, 0, 0);
+        }
+      }
+    }
+    if (isref) {
+      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], p[0], rown, 0, 0, 0);
+      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[1], p[1], rown, 0, 0, 0);
+      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[2], p[2], rown, 0, 0, 0);
+      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[3], p[3], rown, 0, 0, 0);
+      if (jt == 1) {
+        double *xp = xch + (par * NU + u) * 256 + lane;
+        xp[0] = p[0]; xp[64] = p[1]; xp[128] = p[2]; xp[192] = p[3];
+      } else vprev = p;
+      have_prev = true;
+      par ^= 1;
+    } else {
+      dacc += p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
+    }
+  };
+
+  // ---- private (last) ancestors: every unit's sub-panel staged side by side, all waves busy
+  if (pmmax > 0) {
+    double *buf = arena + (size_t)u * 16 * ldS;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = jt + 2 * rr;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (row < p_sr0 && lane + 64 * c < p_Kb + 24) buf[(size_t)row * ldS + lane + 64 * c] = ptmp[rr * 4 + c];
+    }
+    lds_barrier();
+    if (wact && p_sr0 > 0) compute(buf, p_sr0, p_Kb);
+    lds_barrier();
+    if (pmmax > 16) {
+      const int sr = pmu > 16 ? pmu - p_sr0 : 0;
+      if (sr > 0) {
+        const double *src = A.panels + s_ppan[u] + (size_t)p_sr0 * p_Kb + lane;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          double tmp[16];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = jt + 2 * (4 * b + rr);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              tmp[rr * 4 + c] = (row < sr && lane + 64 * c < p_Kb) ? src[(size_t)row * p_Kb + 64 * c] : 0.0;
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = jt + 2 * (4 * b + rr);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (row < sr && lane + 64 * c < p_Kb + 24) buf[(size_t)row * ldS + lane + 64 * c] = tmp[rr * 4 + c];
+          }
+        }
+      }
+      lds_barrier();
+      if (wact && sr > 0) compute(buf, sr, p_Kb);
+      lds_barrier();
+    }
+  }
+
+  STAMP(2);
+  // ---- the shared chain, last ancestor first, in sub-panels of <= 16 rows; the next sub-panel travels from global
+  // memory to registers while the matrix cores work on the current one; two stage buffers, one barrier per sub-panel
+  {
+    double pre[RPW * 4];
+    auto sub_geom = [&](int t, int s, int &r0, int &sr, int &Kb) {
+      const int ma = RFL(s_am[t]);
+      const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
+      r0 = s == 0 ? 0 : sr0;
+      sr = s == 0 ? sr0 : ma - sr0;
+      Kb = RFL(s_ao[t]) + ma;
+    };
+    auto fetch = [&](int t, int s) {
+      int r0, sr, Kb;
+      sub_geom(t, s, r0, sr, Kb);
+      const double *src = A.panels + s_apan[t] + (size_t)(r0 + wid) * Kb + lane;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          pre[rr * 4 + c] = (wid + NW * rr < sr && lane + 64 * c < Kb) ? src[(size_t)(NW * rr) * Kb + 64 * c] : 0.0;
+      }
+    };
+    int t = Jc - 1, s = 0, cur = 0;
+    if (t >= 0) fetch(t, s);
+    while (t >= 0) {
+      int r0, sr, Kb;
+      sub_geom(t, s, r0, sr, Kb);
+      double *buf = arena + (size_t)cur * 16 * ldS;
+      {
+        double *dst = buf + (size_t)wid * ldS + lane;
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (wid + NW * rr < sr && lane + 64 * c < Kb + 24) dst[(size_t)(NW * rr) * ldS + 64 * c] = pre[rr * 4 + c];
+        }
+      }
+      const int nsub = RFL(s_am[t]) > 16 ? 2 : 1;
+      int tn = t, sn = s + 1;
+      if (sn >= nsub) { tn = t - 1; sn = 0; }
+      if (tn >= 0) fetch(tn, sn);
+      lds_barrier();
+      STAMP(3);
+      if (wact) compute(buf, sr, Kb);
+      STAMP(4);
+      cur ^= 1; t = tn; s = sn;
+    }
+  }
+  lds_barrier();
+  if (isref && jt == 0 && two && have_prev) {   // the last sub-panel's off-diagonal Schur update
+    const double *xp = xch + ((par ^ 1) * NU + u) * 256 + lane;
+    const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
+    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, vprev[0], rcross, 0, 0, 0);
+    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, vprev[1], rcross, 0, 0, 0);
+    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, vprev[2], rcross, 0, 0, 0);
+    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, vprev[3], rcross, 0, 0, 0);
+  }
+
+  // ---- hv = T w_pa for this wave's columns (tile rows l4 + 4 r), summed over the 16 chain columns of a tile row
+  {
+    double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
+#pragma unroll
+    for (int n = 0; n < NKT; ++n) {
+      const int k = n * 16 + l15;
+      const double wv = k < Pc ? s_wpa[k] : (k < Pu ? s_pw[u][k - Pc] : 0.0);
+      h0 += tacc[n][0] * wv; h1 += tacc[n][1] * wv; h2 += tacc[n][2] * wv; h3 += tacc[n][3] * wv;
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); h3 += __shfl_xor(h3, o, 64);
+    }
+    if (l15 == 0) {
+      const int j = jt * 16 + l4;
+      s_hv[u][j] = h0; s_hv[u][j + 4] = h1; s_hv[u][j + 8] = h2; s_hv[u][j + 12] = h3;
+    }
+  }
+
+  STAMP(5);
+  double *Ri = arena + (size_t)u * 16 * ldS;   // per unit: Ri [0,1056)  R [1056,2112)  elimination scratch [2112,2328)
+  double *R = Ri + 32 * CH_LD;
+  double *pub = R + 32 * CH_LD;
+  if (!isref) {
+    // ---- leaf units: r_j = 1 / sqrt(K_jj - sum_k V[k][j]^2); panel row of column j = [ -r_j T[j][:] | r_j ]
+    double dsum = dacc;
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    const int jc = jt * 16 + l15;
+    double rj = 0.0;
+    if (jc < Mu) {
+      const double d = cov_entry(cp, s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc], s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc]) - dsum;
+      if (!(d > 0.0)) s_fail[u] = 1;
+      rj = 1.0 / sqrt(d);
+      if (l4 == 0) s_rd[u][jc] = rj;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = jt * 16 + l4 + 4 * r;
+      const double rr = __shfl(rj, l4 + 4 * r, 64);   // lane (0, column) holds that column's r
+      if (j < Mu) {
+        const int bi = s_colblk[u][j];
+        double *prow = A.panels + s_bpan[u][bi] + (size_t)(s_urow0[u] + j - s_brow[u][bi]) * s_bld[u][bi];
+#pragma unroll
+        for (int n = 0; n < NKT; ++n) {
+          const int k = n * 16 + l15;
+          if (k < Pu) prow[k] = -rr * tacc[n][r];
+        }
+        if (l15 == 0) prow[Pu] = rr;
+      }
+    }
+  } else {
+    // ---- reference units: R = K_uu - V'V (lower triangle) from the Schur tiles
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = jt * 16 + l4 + 4 * r, j = jt * 16 + l15;
+      if (i < Mu && j <= i)
+        R[i * CH_LD + j] = cov_entry(cp, s_colx[u][i], s_coly[u][i], s_colmv[u][i], s_colx[u][j], s_coly[u][j], s_colmv[u][j]) - rown[r];
+      if (jt == 0) {
+        const int i2 = 16 + l4 + 4 * r, j2 = l15;
+        if (i2 < Mu)
+          R[i2 * CH_LD + j2] = cov_entry(cp, s_colx[u][i2], s_coly[u][i2], s_colmv[u][i2], s_colx[u][j2], s_coly[u][j2], s_colmv[u][j2]) - rcross[r];
+      }
+    }
+  }
+  STAMP(6);
+  if (anyref) {
+    team_chol_eliminate(R, Ri, isref ? Mu : 0, Mmax, pub, &s_fail[u], ttid);
+    STAMP(7);
+    // ---- N = -Ri T.  Chain tiles alternate between the unit's two waves; the non-owner hands its T tile over through
+    // LDS (slots overlay R and the elimination scratch), so the owner holds T for all of the unit's columns.
+    double *xT = Ri + 32 * CH_LD;
+    constexpr int NR = (NKT + 6) / 7;
+#pragma unroll
+    for (int rho = 0; rho < NR; ++rho) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int kt = rho * 7 + i;
+        if (kt < NKT) {
+          if (isref && kt * 16 < Pu && (i & 1) != jt) {
+            double *sl = xT + i * 256 + lane;
+            sl[0] = tacc[kt][0]; sl[64] = tacc[kt][1]; sl[128] = tacc[kt][2]; sl[192] = tacc[kt][3];
+          }
+        }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int kt = rho * 7 + i;
+        if (kt < NKT) {
+          if (isref && kt * 16 < Pu && (i & 1) == jt) {
+            const double *sl = xT + i * 256 + lane;
+            d4 other;
+            other[0] = sl[0]; other[1] = sl[64]; other[2] = sl[128]; other[3] = sl[192];
+            const d4 T0 = jt == 0 ? tacc[kt] : other, T1 = jt == 0 ? other : tacc[kt];
+            double *pu = A.panels + s_bpan[u][0];
+            const int ld = s_bld[u][0];
+            const int k = kt * 16 + l15;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+              if (it * 16 < Mu) {
+                const int i_a = it * 16 + l15;
+                d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int j = 4 * r + l4;
+                  const double a = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
+                  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T0[r], c, 0, 0, 0);
+                }
+                if (it == 1) {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r) {
+                    const int j = 16 + 4 * r + l4;
+                    const double a = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
+                    if (16 + 4 * r < Mu) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T1[r], c, 0, 0, 0);
+                  }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int io = it * 16 + l4 + 4 * r;
+                  if (io < Mu && k < Pu) pu[(size_t)io * ld + k] = c[r];
+                }
+              }
+            }
+          }
+        }
+      }
+      lds_barrier();
+    }
+    STAMP(8);
+    if (isref) {
+      double *pu = A.panels + s_bpan[u][0];
+      const int ld = s_bld[u][0];
+      for (int idx = ttid; idx < Mu * Mu; idx += 128) {
+        const int i = idx / Mu, j = idx - i * Mu;
+        pu[(size_t)i * ld + Pu + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
+      }
+      if (ttid < Mu) {
+        const int i = ttid;
+        double e = 0.0;
+        for (int j = 0; j <= i; ++j) e += Ri[i * CH_LD + j] * (s_colw[u][j] - s_hv[u][j]);
+        s_e2[u][i] = e * e;
+        s_lg[u][i] = log(Ri[i * CH_LD + i]);
+      }
+    }
+  }
+  lds_barrier();
+  // ---- per-block scalars (logdetCi_comps, loglik_w_comps) and the failure word
+  if (isref) {
+    if (ttid == 0 && Mu > 0) {
+      double wc = 0.0, ldt = 0.0;
+      for (int i = 0; i < Mu; ++i) { wc += s_e2[u][i]; ldt += s_lg[u][i]; }
+      A.logdet_c[s_ublk0[u]] = ldt;
+      A.loglik_c[s_ublk0[u]] = (double)Mu * HL2PI - 0.5 * wc;
+      if (s_fail[u]) atomicMin(A.errflag, s_level * 16 + (s_uJ[u] == 0 ? 1 : 2));
+    }
+  } else {
+    if (ttid < s_unblk[u]) {
+      const int bi = ttid;
+      double wc = 0.0, ldt = 0.0;
+      int cnt = 0;
+      for (int j = 0; j < Mu; ++j)
+        if (s_colblk[u][j] == bi) {
+          const double e = s_rd[u][j] * (s_colw[u][j] - s_hv[u][j]);
+          wc += e * e;
+          ldt += log(s_rd[u][j]);
+          ++cnt;
+        }
+      A.logdet_c[s_ublk0[u] + bi] = ldt;
+      A.loglik_c[s_ublk0[u] + bi] = (double)cnt * HL2PI - 0.5 * wc;
+    }
+    if (ttid == 0 && Mu > 0 && s_fail[u]) atomicMin(A.errflag, s_level * 16 + 3);
+  }
+  STAMP(9);
+  STAMP_FLUSH;
+}

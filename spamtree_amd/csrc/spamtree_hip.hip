@@ -58,22 +58,51 @@ struct Blk {
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
+// exp(x) for the covariance kernels: two-step Cody-Waite reduction to |r| <= ln2/2, degree-13 Taylor polynomial
+// (truncation error < 5e-18), v_ldexp_f64 for the scaling (overflow -> inf, underflow -> denormals / 0 as in libm).
+// About half the instructions of the library routine; relative error < 2e-16.
+__device__ __forceinline__ double cov_exp(double x) {
+  const double t = __builtin_rint(x * 1.44269504088896338700e+00);
+  double r = fma(t, -6.93147180369123816490e-01, x);
+  r = fma(t, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;            // 1/13!
+  p = fma(p, r, 2.0876756987868100e-09);        // 1/12!
+  p = fma(p, r, 2.5052108385441720e-08);        // 1/11!
+  p = fma(p, r, 2.7557319223985893e-07);        // 1/10!
+  p = fma(p, r, 2.7557319223985888e-06);        // 1/9!
+  p = fma(p, r, 2.4801587301587302e-05);        // 1/8!
+  p = fma(p, r, 1.9841269841269841e-04);        // 1/7!
+  p = fma(p, r, 1.3888888888888889e-03);        // 1/6!
+  p = fma(p, r, 8.3333333333333332e-03);        // 1/5!
+  p = fma(p, r, 4.1666666666666664e-02);        // 1/4!
+  p = fma(p, r, 1.6666666666666666e-01);        // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  const double tc = fmin(fmax(t, -2000.0), 2000.0);
+  return __builtin_ldexp(p, (int)tc);
+}
+
 __device__ __forceinline__ double cov_entry(const CovPar &c, double xi, double yi, int vi, double xj, double yj, int vj) {
   const double dx = xi - xj, dy = yi - yj;
   const double h = sqrt(dx * dx + dy * dy);
-  if (c.q == 1) return c.ai1[0] * exp(-c.tmv[0] * h);  // cexpcov: sigmasq = ai1(0), phi = thetamv(0)
+  if (c.q == 1) return c.ai1[0] * cov_exp(-c.tmv[0] * h);  // cexpcov: sigmasq = ai1(0), phi = thetamv(0)
   const double v = c.D[vi * c.q + vj];
   double cb;  // C_base(h, 0, v)
   if (c.q > 2) {
     const double ps = exp(0.5 * c.tmv[1] * log1p(c.tmv[0] * v));
-    cb = exp(-c.tmv[2] * (h / ps)) / (ps * ps);
+    cb = cov_exp(-c.tmv[2] * (h / ps)) / (ps * ps);
   } else {
     const double ps = sqrt(v + 1.0);
-    cb = exp(-c.tmv[0] * (h / ps)) / (v + 1.0);
+    cb = cov_exp(-c.tmv[0] * (h / ps)) / (v + 1.0);
   }
-  if (v == 0.0) return c.ai1[vi] * c.ai1[vi] * cb + c.ai2[vi] * c.ai2[vi] * exp(-c.phi[vi] * h);
+  if (v == 0.0) return c.ai1[vi] * c.ai1[vi] * cb + c.ai2[vi] * c.ai2[vi] * cov_exp(-c.phi[vi] * h);
   return c.ai1[vi] * c.ai1[vj] * cb;
 }
+
+// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for global loads in flight
+// (a prefetched sub-panel keeps travelling across it) nor for global stores
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -1348,6 +1377,8 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma2(Fast2Args A, CovPar cp) 
 // ---------------------------------------------------------------------------------------------------------------
 // Phase B: block-Gibbs draw of w_u + message push (spamtree_model.cpp:1011-1226), one workgroup per block.
 // ---------------------------------------------------------------------------------------------------------------
+#include "factor_quad.hpp"
+
 struct SampleArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -2004,6 +2035,8 @@ struct LevelInfo {
   size_t lds_sfast = 0;
   int stg2 = 0, x_dbl2 = 0, nkx2 = 0;                    // k_factor_mfma2 geometry (0 = not eligible)
   size_t lds_fast2 = 0;
+  int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
+  size_t lds_quad = 0;
   int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
 };
 
@@ -2024,6 +2057,9 @@ struct st_handle_s {
   std::vector<int> anc_idx, dch_idx, lvl_list, pred_list, all_obs_list;
   std::vector<Grp> grps;
   DevBuf<Grp> d_grps;
+  std::vector<Quad> quads;
+  DevBuf<Quad> d_quads;
+  int quad_nu = 4;
   // multi-GPU sharding
   int rank = 0, world = 1, cut = 0;
   std::vector<int> blk_owner;                 // device block -> owning rank, -1 = replicated
@@ -2150,7 +2186,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free();
+  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free();
   h->d_ownobs.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
@@ -2370,6 +2406,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) h->lds_limit = (size_t)v;
     if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
+    { const char *e = getenv("SPAMTREE_QUAD_NU"); h->quad_nu = (e && e[0] == '2') ? 2 : 4; }
   }
   h->levels.resize(n_actual);
   auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
@@ -2528,6 +2565,45 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         L.gown_lo = glo < ghi ? glo : 0; L.gown_n = glo < ghi ? ghi - glo : 0;
       }
     }
+    // quads for k_factor_quad: runs of up to quad_nu column groups of one rank that share their ancestor chain
+    // (reference levels) or the chain without its last ancestor (leaf levels: cousins)
+    L.quad_first = (int)h->quads.size(); L.quad_count = 0; L.q_nkx = 0; L.qown_lo = 0; L.qown_n = 0;
+    if (L.fast && L.maxP > 0 && L.maxP <= 200 && L.maxMa <= 32) {
+      int k = 0, qlo = INT_MAX, qhi = 0;
+      bool mixed = false;
+      while (k < L.grp_count) {
+        const Grp &G0 = h->grps[L.grp_first + k];
+        const Blk &B0 = h->blks[G0.blk0];
+        const int J = B0.nanc, Jc = B0.isref ? J : std::max(J - 1, 0);
+        if ((B0.isref != 0) != (L.isref != 0)) mixed = true;
+        Quad Qd;
+        Qd.g0 = k; Qd.nu = 1; Qd.Jc = Jc; Qd.Pc = 0;
+        for (int t = 0; t < Jc; ++t) Qd.Pc += h->blks[h->anc_idx[B0.anc_ptr + t]].m;
+        while (Qd.nu < h->quad_nu && k + Qd.nu < L.grp_count) {
+          const Grp &G1 = h->grps[L.grp_first + k + Qd.nu];
+          const Blk &B1 = h->blks[G1.blk0];
+          if (B1.nanc != J || B1.isref != B0.isref || h->blk_owner[G1.blk0] != h->blk_owner[G0.blk0]) break;
+          bool same = true;
+          for (int t = 0; t < Jc && same; ++t) same = h->anc_idx[B1.anc_ptr + t] == h->anc_idx[B0.anc_ptr + t];
+          if (!same) break;
+          ++Qd.nu;
+        }
+        const bool mine = g < h->cut || h->blk_owner[G0.blk0] == h->rank;
+        if (mine) { qlo = std::min(qlo, L.quad_count); qhi = std::max(qhi, L.quad_count + 1); }
+        h->quads.push_back(Qd);
+        L.quad_count++;
+        k += Qd.nu;
+      }
+      L.qown_lo = qlo < qhi ? qlo : 0; L.qown_n = qlo < qhi ? qhi - qlo : 0;
+      const int need = (L.maxP + 3) / 4;
+      L.q_nkx = need <= 32 ? 32 : (need <= 38 ? 38 : (need <= 44 ? 44 : 50));
+      int ldS = std::max(std::max(L.maxP + 24, 4 * L.q_nkx + 4), 178);
+      while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
+      L.q_ldS = ldS;
+      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (size_t)2 * h->quad_nu * 256) * 8;
+      if (L.grp_count < 2 * L.quad_count || mixed) L.q_nkx = 0;   // mostly singletons: nothing to share
+      if (L.isref && L.q_nkx == 50) L.q_nkx = 0;                   // that instantiation spills registers: k_factor_mfma is faster
+    }
   }
   for (int i = 0; i < nb; ++i) {
     const Blk &B = h->blks[i];
@@ -2609,6 +2685,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   { std::vector<int> a = h->dch_idx; if (a.empty()) a.push_back(0); CCHK(h->d_dch.upload(a)); }
   CCHK(h->d_lvl.upload(h->lvl_list));
   { std::vector<Grp> g = h->grps; if (g.empty()) g.push_back(Grp{0, 0, 0, 0, 0}); CCHK(h->d_grps.upload(g)); }
+  { std::vector<Quad> g = h->quads; if (g.empty()) g.push_back(Quad{0, 0, 0, 0}); CCHK(h->d_quads.upload(g)); }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
   { std::vector<int> a = h->own_obs_list; if (a.empty()) a.push_back(0); CCHK(h->d_ownobs.upload(a)); }
@@ -2667,7 +2744,26 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     // double-buffered stage): same results, same speed on MI355X today, kept as the base of the
     // wave-specialised version
     const char *e = getenv("SPAMTREE_FACTOR_KERNEL");
-    h->factor_gen = (e && e[0] == '2') ? 2 : 1;
+    h->factor_gen = (e && e[0] == '2') ? 2 : ((e && e[0] == '3') ? 3 : 1);
+  }
+  {
+    // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
+    const void *fq = h->quad_nu == 4 ? (const void *)k_factor_quad<4, 50, 13, false> : (const void *)k_factor_quad<2, 50, 13, false>;
+    hipFuncAttributes fa;
+    size_t stat = 24 * 1024;
+    if (hipFuncGetAttributes(&fa, fq) == hipSuccess) stat = fa.sharedSizeBytes;
+    for (auto &L : h->levels) {
+      if (L.q_nkx == 0) continue;
+      int minq = h->sm_count / 2;
+      { const char *e = getenv("SPAMTREE_QUAD_MIN"); if (e) minq = atoi(e); }
+      if (L.lds_quad + stat > 160 * 1024 || L.qown_n < minq) L.q_nkx = 0;
+    }
+#define QATTR(NU_, NKX_, NKT_)                                                                                                       \
+  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
+  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat)
+    QATTR(4, 50, 13); QATTR(4, 44, 11); QATTR(4, 38, 10); QATTR(4, 32, 8);
+    QATTR(2, 50, 13); QATTR(2, 44, 11); QATTR(2, 38, 10); QATTR(2, 32, 8);
+#undef QATTR
   }
   (void)hipGetLastError();
 #undef CCHK
@@ -2848,7 +2944,25 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
     A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
     {
       ProfScope ps(h, 0, g);
-      if (L.fast && h->factor_gen == 2 && L.nkx2 > 0) {
+      if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) {
+        QuadArgs F;
+        std::memset(&F, 0, sizeof(F));
+        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first;
+        F.quads = h->d_quads.p + L.quad_first + L.qown_lo; F.nquad = L.qown_n;
+        F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
+        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p; F.ldS = L.q_ldS;
+#define QLAUNCH(NU_, NKX_, NKT_)                                                                                               \
+  do {                                                                                                                         \
+    if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp); \
+    else hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, false>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp);         \
+  } while (0)
+        if (h->quad_nu == 4) {
+          if (L.q_nkx == 32) QLAUNCH(4, 32, 8); else if (L.q_nkx == 38) QLAUNCH(4, 38, 10); else if (L.q_nkx == 44) QLAUNCH(4, 44, 11); else QLAUNCH(4, 50, 13);
+        } else {
+          if (L.q_nkx == 32) QLAUNCH(2, 32, 8); else if (L.q_nkx == 38) QLAUNCH(2, 38, 10); else if (L.q_nkx == 44) QLAUNCH(2, 44, 11); else QLAUNCH(2, 50, 13);
+        }
+#undef QLAUNCH
+      } else if (L.fast && h->factor_gen == 2 && L.nkx2 > 0) {
         Fast2Args F;
         std::memset(&F, 0, sizeof(F));
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
