@@ -37,10 +37,10 @@ struct QuadArgs {
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
 };
 
-#define TCH_EPT 9
 // Team version of block_chol_eliminate: the workgroup is split into teams of 128 threads, each team eliminates its own
 // m x m matrix ([A | I] -> [L | L^{-1}]); all teams run the same pivot loop (mmax = largest m, uniform) and share its
 // barrier.  A: LDS, row stride CH_LD, lower triangle valid; Bm receives L^{-1} (lower); pub: 216 doubles per team.
+template <int TCH_EPT>
 __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
   const int nA = m * (m + 1) / 2, nE = 2 * nA;
   lds_barrier();
@@ -97,6 +97,19 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
 
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
+// One row of Kb doubles, global -> LDS, by LDS-DMA (16 bytes per lane, 1 KiB per wave-instruction, no registers): lane l
+// moves doubles 2l, 2l+1 of each 128-double piece.  The source needs 8-byte alignment only.  When Kb is odd the last
+// active lane also drops the row's successor into column Kb: the caller zero-fills [Kb, Kb+24) after the data has landed.
+// `two`: issue the second piece (wave-uniform; callers that count instructions pass Kb > 128).
+typedef __attribute__((address_space(3))) void q_lds_void;
+typedef __attribute__((address_space(1))) const void q_glb_void;
+__device__ __forceinline__ void dma_row(const double *src, double *dst, int Kb, int lane, bool two) {
+  if (2 * lane < Kb) __builtin_amdgcn_global_load_lds((q_glb_void *)(src + 2 * lane), (q_lds_void *)dst, 16, 0, 0);
+  if (two) {
+    if (128 + 2 * lane < Kb) __builtin_amdgcn_global_load_lds((q_glb_void *)(src + 128 + 2 * lane), (q_lds_void *)(dst + 128), 16, 0, 0);
+  }
+}
+
 template <int NU, int NKX, int NKT, bool ISREF>
 __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar cp) {
   constexpr int NTQ = 128 * NU, NW = 2 * NU, NC = 32 * NU, RPW = 16 / NW;
@@ -107,11 +120,16 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
   __shared__ int s_uM[NU], s_uP[NU], s_ublk0[NU], s_unblk[NU], s_uref[NU], s_uJ[NU], s_pm[NU], s_fail[NU], s_level;
   __shared__ long long s_urow0[NU], s_prow[NU], s_ppan[NU];
-  __shared__ long long s_bpan[NU][32], s_brow[NU][32];
-  __shared__ int s_bld[NU][32];
-  __shared__ double s_colx[NU][32], s_coly[NU][32], s_colw[NU][32], s_hv[NU][32], s_rd[NU][32], s_px[NU][32], s_py[NU][32], s_pw[NU][32];
-  __shared__ double s_e2[NU][32], s_lg[NU][32];
-  __shared__ int s_colmv[NU][32], s_colblk[NU][32], s_pmv[NU][32];
+  constexpr int NB = ISREF ? 1 : 32, NUL = ISREF ? 1 : NU, NUR = ISREF ? NU : 1;   // leaf-only / reference-only arrays
+  __shared__ long long s_bpan[NU][NB], s_brow[NU][NB];
+  __shared__ int s_bld[NU][NB];
+  __shared__ double s_colx[NU][32], s_coly[NU][32], s_colw[NU][32], s_hv[NU][32];
+  __shared__ double s_rd[NUL][32], s_px[NUL][32], s_py[NUL][32], s_pw[NUL][32];
+  __shared__ double s_e2[NUR][32], s_lg[NUR][32];
+  __shared__ int s_colmv[NU][32], s_colblk[NUL][32], s_pmv[NUL][32];
+  struct SubIt { int geo, Kb, pend, pad; long long src, pad2; };   // one staged sub-panel: geo = sr | r0 << 8
+  __shared__ SubIt s_it[2 * MAXJ];
+  __shared__ int s_nit;
   __shared__ double s_sx[PMAX], s_sy[PMAX], s_wpa[PMAX];
   __shared__ int s_smv[PMAX];
 
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   const int ldS = A.ldS;
   double *arena = lds;
   double *zrow = arena + (size_t)NU * 16 * ldS;   // a row of zeros
-  double *xch = zrow + ldS;                       // V tiles of the jt = 1 waves: [2][NU][256]
+  double *xch = zrow + ldS;                       // reference quads only: V tiles of the jt = 1 waves, [2][NU][256]
 
   STAMP_DECL
   int qidx = blockIdx.x;
@@ -160,9 +178,23 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     int o = 0;
     for (int t = 0; t < Jc; ++t) { s_ao[t] = o; o += s_am[t]; }
     s_ao[Jc] = o;
+    // the staged sub-panels of the shared chain in processing order (last ancestor first, <= 16 rows each)
+    int n = 0;
+    for (int t = Jc - 1; t >= 0; --t) {
+      const int ma = s_am[t], sr0 = ma > 16 ? (ma + 1) >> 1 : ma, Kb = s_ao[t] + ma;
+      for (int sp = 0; sp < (ma > 16 ? 2 : 1); ++sp) {
+        const int r0 = sp == 0 ? 0 : sr0, sr = sp == 0 ? sr0 : ma - sr0;
+        SubIt it;
+        it.geo = sr | (r0 << 8); it.Kb = Kb; it.pend = 0; it.pad = 0; it.src = s_apan[t] + (long long)r0 * Kb; it.pad2 = 0;
+        s_it[n] = it;
+        if (n > 0) s_it[n - 1].pend = Kb > 128 ? 2 * RPW : RPW;   // DMA instructions per wave of the following sub-panel
+        ++n;
+      }
+    }
+    s_nit = n;
   }
-  for (int e = tid; e < NU * 32; e += NTQ) {
-    const int uu = e >> 5, b = e & 31;
+  for (int e = tid; e < NU * NB; e += NTQ) {
+    const int uu = e / NB, b = e - uu * NB;
     if (b < s_unblk[uu]) {
       const Blk Bb = A.blks[s_ublk0[uu] + b];
       s_bpan[uu][b] = Bb.panel_off; s_brow[uu][b] = Bb.row0; s_bld[uu][b] = Bb.ld;
@@ -189,34 +221,25 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   for (int e = tid; e < NU * 32; e += NTQ) {
     const int uu = e >> 5, i = e & 31;
     double x = 0.0, y = 0.0, ww = 0.0; int v = 0;
-    if (i < s_pm[uu]) { const long long r = s_prow[uu] + i; x = A.cx[r]; y = A.cy[r]; ww = A.w[r]; v = A.mv[r]; }
-    s_px[uu][i] = x; s_py[uu][i] = y; s_pw[uu][i] = ww; s_pmv[uu][i] = v;
-    x = 0.0; y = 0.0; ww = 0.0; v = 0;
+    if constexpr (!ISREF) {
+      if (i < s_pm[uu]) { const long long r = s_prow[uu] + i; x = A.cx[r]; y = A.cy[r]; ww = A.w[r]; v = A.mv[r]; }
+      s_px[uu][i] = x; s_py[uu][i] = y; s_pw[uu][i] = ww; s_pmv[uu][i] = v;
+      x = 0.0; y = 0.0; ww = 0.0; v = 0;
+    }
     int bi = 0;
     if (i < s_uM[uu]) {
       const long long r = s_urow0[uu] + i;
       x = A.cx[r]; y = A.cy[r]; ww = A.w[r]; v = A.mv[r];
-      while (bi + 1 < s_unblk[uu] && r >= s_brow[uu][bi + 1]) ++bi;
+      if constexpr (!ISREF) { while (bi + 1 < s_unblk[uu] && r >= s_brow[uu][bi + 1]) ++bi; }
     }
-    s_colx[uu][i] = x; s_coly[uu][i] = y; s_colw[uu][i] = ww; s_colmv[uu][i] = v; s_colblk[uu][i] = bi;
+    s_colx[uu][i] = x; s_coly[uu][i] = y; s_colw[uu][i] = ww; s_colmv[uu][i] = v;
+    if constexpr (!ISREF) s_colblk[uu][i] = bi;
   }
   __syncthreads();
 
   STAMP(0);
-  // ---- private (last) ancestors, first sub-panel: the loads start now and travel while K is evaluated
   const int p_sr0 = pmu > 16 ? (pmu + 1) >> 1 : pmu;   // rows of the first private sub-panel
   const int p_Kb = Pc + pmu;
-  double ptmp[32];
-  if (pmmax > 0) {
-    const double *src = A.panels + s_ppan[u] + lane;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = jt + 2 * rr;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        ptmp[rr * 4 + c] = (row < p_sr0 && lane + 64 * c < p_Kb) ? src[(size_t)row * p_Kb + 64 * c] : 0.0;
-    }
-  }
 
   // ---- K_{pa,u}: every lane evaluates the B operands of its own K-steps, kx[st] = K[4 st + l4][column jt*16 + l15 of
   // unit u], in a rolled loop (one covariance body per pass) through lane-private LDS slots, then picks them up with
@@ -238,8 +261,10 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
           double v = 0.0;
           if (cok && k < Pu) {
             double ax, ay; int av;
-            if (k < Pc) { ax = s_sx[k]; ay = s_sy[k]; av = s_smv[k]; }
-            else { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
+            ax = s_sx[min(k, PMAX - 1)]; ay = s_sy[min(k, PMAX - 1)]; av = s_smv[min(k, PMAX - 1)];
+            if constexpr (!ISREF) {
+              if (k >= Pc) { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
+            }
             v = cov_entry(cp, ax, ay, av, mx, my, mvj);
           }
           kb[i * 64] = v;
@@ -325,95 +350,77 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     }
   };
 
-  // ---- private (last) ancestors: every unit's sub-panel staged side by side, all waves busy
-  if (pmmax > 0) {
+  // ---- private (last) ancestors: every unit's sub-panel staged side by side (LDS-DMA), all waves busy
+  if constexpr (!ISREF) if (pmmax > 0) {
     double *buf = arena + (size_t)u * 16 * ldS;
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = jt + 2 * rr;
+    for (int sp = 0; sp < 2; ++sp) {
+      if (sp == 0 || pmmax > 16) {
+        const int r0 = sp == 0 ? 0 : p_sr0;
+        const int sr = sp == 0 ? p_sr0 : (pmu > 16 ? pmu - p_sr0 : 0);
+        const double *src = A.panels + s_ppan[u] + (size_t)r0 * p_Kb;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (row < p_sr0 && lane + 64 * c < p_Kb + 24) buf[(size_t)row * ldS + lane + 64 * c] = ptmp[rr * 4 + c];
-    }
-    lds_barrier();
-    if (wact && p_sr0 > 0) compute(buf, p_sr0, p_Kb);
-    lds_barrier();
-    if (pmmax > 16) {
-      const int sr = pmu > 16 ? pmu - p_sr0 : 0;
-      if (sr > 0) {
-        const double *src = A.panels + s_ppan[u] + (size_t)p_sr0 * p_Kb + lane;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          double tmp[16];
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int row = jt + 2 * (4 * b + rr);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              tmp[rr * 4 + c] = (row < sr && lane + 64 * c < p_Kb) ? src[(size_t)row * p_Kb + 64 * c] : 0.0;
-          }
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int row = jt + 2 * (4 * b + rr);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              if (row < sr && lane + 64 * c < p_Kb + 24) buf[(size_t)row * ldS + lane + 64 * c] = tmp[rr * 4 + c];
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = jt + 2 * rr;
+          if (row < sr) {
+            dma_row(src + (size_t)row * p_Kb, buf + (size_t)row * ldS, p_Kb, lane, true);
           }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          const int row = jt + 2 * rr;
+          if (row < sr && lane < 24) buf[(size_t)row * ldS + p_Kb + lane] = 0.0;
+        }
+        lds_barrier();
+        if (wact && sr > 0) compute(buf, sr, p_Kb);
+        lds_barrier();
       }
-      lds_barrier();
-      if (wact && sr > 0) compute(buf, sr, p_Kb);
-      lds_barrier();
     }
   }
 
   STAMP(2);
-  // ---- the shared chain, last ancestor first, in sub-panels of <= 16 rows; the next sub-panel travels from global
-  // memory to registers while the matrix cores work on the current one; two stage buffers, one barrier per sub-panel
+  // ---- the shared chain, last ancestor first, in sub-panels of <= 16 rows.  Sub-panels travel from global memory
+  // straight into a ring of LDS buffers (LDS-DMA, no registers): the one after next is requested while the matrix
+  // cores work on the current one; one LDS-only barrier per sub-panel.
   {
-    double pre[RPW * 4];
-    auto sub_geom = [&](int t, int s, int &r0, int &sr, int &Kb) {
-      const int ma = RFL(s_am[t]);
-      const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
-      r0 = s == 0 ? 0 : sr0;
-      sr = s == 0 ? sr0 : ma - sr0;
-      Kb = RFL(s_ao[t]) + ma;
-    };
-    auto fetch = [&](int t, int s) {
-      int r0, sr, Kb;
-      sub_geom(t, s, r0, sr, Kb);
-      const double *src = A.panels + s_apan[t] + (size_t)(r0 + wid) * Kb + lane;
+    constexpr int D = NU >= 3 ? 3 : 2;   // ring depth (the arena holds NU buffers)
+    const int nit = RFL(s_nit);
+    // every wave issues exactly RPW * (Kb > 128 ? 2 : 1) DMA instructions per sub-panel (rows beyond sr re-read row sr-1)
+    auto issue = [&](int i, double *buf) {
+      const SubIt it = s_it[i];
+      const int sr = RFL(it.geo) & 255, Kb = RFL(it.Kb);
+      const double *base = A.panels + it.src;
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          pre[rr * 4 + c] = (wid + NW * rr < sr && lane + 64 * c < Kb) ? src[(size_t)(NW * rr) * Kb + 64 * c] : 0.0;
+        const int row = wid + NW * rr;
+        dma_row(base + (size_t)min(row, sr - 1) * Kb, buf + (size_t)row * ldS, Kb, lane, Kb > 128);
       }
     };
-    int t = Jc - 1, s = 0, cur = 0;
-    if (t >= 0) fetch(t, s);
-    while (t >= 0) {
-      int r0, sr, Kb;
-      sub_geom(t, s, r0, sr, Kb);
+    int iq = 0, slot_q = 0;   // next sub-panel to request and its ring slot
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (iq < nit) { issue(iq, arena + (size_t)slot_q * 16 * ldS); ++iq; slot_q = slot_q + 1 == D ? 0 : slot_q + 1; }
+    int cur = 0;
+    for (int i = 0; i < nit; ++i) {
+      const int geo = RFL(s_it[i].geo), Kb = RFL(s_it[i].Kb), pend = (D == 3) ? RFL(s_it[i].pend) : 0;
+      const int sr = geo & 255;
       double *buf = arena + (size_t)cur * 16 * ldS;
-      {
-        double *dst = buf + (size_t)wid * ldS + lane;
+      // this wave's own requests for the current sub-panel have landed once at most the next sub-panel's remain in flight
+      if (pend == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (pend == RPW) { if (RPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      else { if (RPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (wid + NW * rr < sr && lane + 64 * c < Kb + 24) dst[(size_t)(NW * rr) * ldS + 64 * c] = pre[rr * 4 + c];
-        }
-      }
-      const int nsub = RFL(s_am[t]) > 16 ? 2 : 1;
-      int tn = t, sn = s + 1;
-      if (sn >= nsub) { tn = t - 1; sn = 0; }
-      if (tn >= 0) fetch(tn, sn);
+      for (int rr = 0; rr < RPW; ++rr)
+        if (lane < 24) buf[(size_t)(wid + NW * rr) * ldS + Kb + lane] = 0.0;   // also wipes the DMA's odd-Kb overshoot
+      STAMP(5);
       lds_barrier();
       STAMP(3);
+      if (iq < nit) { issue(iq, arena + (size_t)slot_q * 16 * ldS); ++iq; slot_q = slot_q + 1 == D ? 0 : slot_q + 1; }
+      STAMP(6);
       if (wact) compute(buf, sr, Kb);
       STAMP(4);
-      cur ^= 1; t = tn; s = sn;
+      cur = cur + 1 == D ? 0 : cur + 1;
     }
   }
   lds_barrier();
@@ -432,7 +439,8 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
 #pragma unroll
     for (int n = 0; n < NKT; ++n) {
       const int k = n * 16 + l15;
-      const double wv = k < Pc ? s_wpa[k] : (k < Pu ? s_pw[u][k - Pc] : 0.0);
+      double wv = k < Pc ? s_wpa[k] : 0.0;
+      if constexpr (!ISREF) { if (k >= Pc && k < Pu) wv = s_pw[u][k - Pc]; }
       h0 += tacc[n][0] * wv; h1 += tacc[n][1] * wv; h2 += tacc[n][2] * wv; h3 += tacc[n][3] * wv;
     }
 #pragma unroll
@@ -445,11 +453,11 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     }
   }
 
-  STAMP(5);
+  STAMP(10);
   double *Ri = arena + (size_t)u * 16 * ldS;   // per unit: Ri [0,1056)  R [1056,2112)  elimination scratch [2112,2328)
   double *R = Ri + 32 * CH_LD;
   double *pub = R + 32 * CH_LD;
-  if (!isref) {
+  if constexpr (!ISREF) {
     // ---- leaf units: r_j = 1 / sqrt(K_jj - sum_k V[k][j]^2); panel row of column j = [ -r_j T[j][:] | r_j ]
     double dsum = dacc;
     dsum += __shfl_xor(dsum, 16, 64);
@@ -491,9 +499,11 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       }
     }
   }
-  STAMP(6);
-  if (anyref) {
-    team_chol_eliminate(R, Ri, isref ? Mu : 0, Mmax, pub, &s_fail[u], ttid);
+  STAMP(11);
+  if constexpr (ISREF) {
+    // element slots per thread: m (m + 1) <= 128 * slots
+    if (Mmax <= 27) team_chol_eliminate<6>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
+    else team_chol_eliminate<9>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
     STAMP(7);
     // ---- N = -Ri T.  Chain tiles alternate between the unit's two waves; the non-owner hands its T tile over through
     // LDS (slots overlay R and the elimination scratch), so the owner holds T for all of the unit's columns.
@@ -572,9 +582,11 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       }
     }
   }
+  STAMP(12);
   lds_barrier();
+  STAMP(9);
   // ---- per-block scalars (logdetCi_comps, loglik_w_comps) and the failure word
-  if (isref) {
+  if constexpr (ISREF) {
     if (ttid == 0 && Mu > 0) {
       double wc = 0.0, ldt = 0.0;
       for (int i = 0; i < Mu; ++i) { wc += s_e2[u][i]; ldt += s_lg[u][i]; }
@@ -599,6 +611,6 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     }
     if (ttid == 0 && Mu > 0 && s_fail[u]) atomicMin(A.errflag, s_level * 16 + 3);
   }
-  STAMP(9);
+  STAMP(13);
   STAMP_FLUSH;
 }

@@ -579,9 +579,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #ifdef FM_STAMPS
 // diagnostic build only (never shipped): per-section shader-clock totals of k_factor_mfma, thread 0 of every workgroup
 __device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_acc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long st_t0 = clock64(), st_t1 = 0;
+#define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_t0 = clock64(), st_t1 = 0;
 #define STAMP(slot) do { st_t1 = clock64(); st_acc[slot] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
-#define STAMP_FLUSH do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 10; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); } } while (0)
+#define STAMP_FLUSH do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); } } while (0)
 extern "C" int st_debug_stamps(unsigned long long *out, int reset) {
   if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
@@ -2406,7 +2406,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) h->lds_limit = (size_t)v;
     if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
-    { const char *e = getenv("SPAMTREE_QUAD_NU"); h->quad_nu = (e && e[0] == '2') ? 2 : 4; }
+    h->quad_nu = 4;   // units per workgroup of k_factor_quad (2 per workgroup with two workgroups per CU measured slower)
   }
   h->levels.resize(n_actual);
   auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
@@ -2600,7 +2600,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       int ldS = std::max(std::max(L.maxP + 24, 4 * L.q_nkx + 4), 178);
       while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
       L.q_ldS = ldS;
-      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (size_t)2 * h->quad_nu * 256) * 8;
+      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)2 * h->quad_nu * 256 : 0)) * 8;
       if (L.grp_count < 2 * L.quad_count || mixed) L.q_nkx = 0;   // mostly singletons: nothing to share
       if (L.isref && L.q_nkx == 50) L.q_nkx = 0;                   // that instantiation spills registers: k_factor_mfma is faster
     }
@@ -2698,8 +2698,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   CCHK(h->d_B.alloc((size_t)pb->p * pb->q));
   CCHK(h->d_tsq.alloc(QMAX));
   for (int s = 0; s < 2; ++s) {
-    CCHK(h->d_panels[s].alloc(h->panel_total));
-    CCHK(hipMemset(h->d_panels[s].p, 0, h->panel_total * sizeof(double)));
+    CCHK(h->d_panels[s].alloc(h->panel_total + 2));   // + 2: a 16-byte LDS-DMA piece may read one double past a row
+    CCHK(hipMemset(h->d_panels[s].p, 0, (h->panel_total + 2) * sizeof(double)));
     CCHK(h->d_logdet[s].alloc(nb)); CCHK(h->d_loglik[s].alloc(nb));
     CCHK(hipMemset(h->d_logdet[s].p, 0, nb * sizeof(double)));
     CCHK(hipMemset(h->d_loglik[s].p, 0, nb * sizeof(double)));
@@ -2748,10 +2748,14 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   }
   {
     // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
-    const void *fq = h->quad_nu == 4 ? (const void *)k_factor_quad<4, 50, 13, false> : (const void *)k_factor_quad<2, 50, 13, false>;
+    const void *fq = (const void *)k_factor_quad<4, 50, 13, false>;
     hipFuncAttributes fa;
     size_t stat = 24 * 1024;
     if (hipFuncGetAttributes(&fa, fq) == hipSuccess) stat = fa.sharedSizeBytes;
+    {
+      const void *fr = (const void *)k_factor_quad<4, 50, 13, true>;
+      if (hipFuncGetAttributes(&fa, fr) == hipSuccess) stat = std::max(stat, (size_t)fa.sharedSizeBytes);
+    }
     for (auto &L : h->levels) {
       if (L.q_nkx == 0) continue;
       int minq = h->sm_count / 2;
@@ -2762,7 +2766,6 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
   (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat)
     QATTR(4, 50, 13); QATTR(4, 44, 11); QATTR(4, 38, 10); QATTR(4, 32, 8);
-    QATTR(2, 50, 13); QATTR(2, 44, 11); QATTR(2, 38, 10); QATTR(2, 32, 8);
 #undef QATTR
   }
   (void)hipGetLastError();
@@ -2956,11 +2959,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
     if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp); \
     else hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, false>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp);         \
   } while (0)
-        if (h->quad_nu == 4) {
-          if (L.q_nkx == 32) QLAUNCH(4, 32, 8); else if (L.q_nkx == 38) QLAUNCH(4, 38, 10); else if (L.q_nkx == 44) QLAUNCH(4, 44, 11); else QLAUNCH(4, 50, 13);
-        } else {
-          if (L.q_nkx == 32) QLAUNCH(2, 32, 8); else if (L.q_nkx == 38) QLAUNCH(2, 38, 10); else if (L.q_nkx == 44) QLAUNCH(2, 44, 11); else QLAUNCH(2, 50, 13);
-        }
+        if (L.q_nkx == 32) QLAUNCH(4, 32, 8); else if (L.q_nkx == 38) QLAUNCH(4, 38, 10); else if (L.q_nkx == 44) QLAUNCH(4, 44, 11); else QLAUNCH(4, 50, 13);
 #undef QLAUNCH
       } else if (L.fast && h->factor_gen == 2 && L.nkx2 > 0) {
         Fast2Args F;
