@@ -112,7 +112,7 @@ __device__ __forceinline__ void dma_row(const double *src, double *dst, int Kb, 
 
 template <int NU, int NKX, int NKT, bool ISREF>
 __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar cp) {
-  constexpr int NTQ = 128 * NU, NW = 2 * NU, NC = 32 * NU, RPW = 16 / NW;
+  constexpr int NTQ = 128 * NU, NW = 2 * NU;
   constexpr int PMAX = 4 * NKX, KH = (NKX + 1) / 2;   // K-steps evaluated per pass through the arena
   static_assert(NKT * 16 >= PMAX, "T tiles must cover the chain");
   extern __shared__ double lds[];
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ double s_rd[NUL][32], s_px[NUL][32], s_py[NUL][32], s_pw[NUL][32];
   __shared__ double s_e2[NUR][32], s_lg[NUR][32];
   __shared__ int s_colmv[NU][32], s_colblk[NUL][32], s_pmv[NUL][32];
-  struct SubIt { int geo, Kb, pend, pad; long long src, pad2; };   // one staged sub-panel: geo = sr | r0 << 8
-  __shared__ SubIt s_it[2 * MAXJ];
+  struct SubIt { int geo, Kb, pend, pad; long long src, pad2; };   // one staged panel of the shared chain: geo = rows
+  __shared__ SubIt s_it[MAXJ];
   __shared__ int s_nit;
   __shared__ double s_sx[PMAX], s_sy[PMAX], s_wpa[PMAX];
   __shared__ int s_smv[PMAX];
@@ -178,18 +178,12 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     int o = 0;
     for (int t = 0; t < Jc; ++t) { s_ao[t] = o; o += s_am[t]; }
     s_ao[Jc] = o;
-    // the staged sub-panels of the shared chain in processing order (last ancestor first, <= 16 rows each)
+    // the staged panels of the shared chain in processing order (last ancestor first)
     int n = 0;
     for (int t = Jc - 1; t >= 0; --t) {
-      const int ma = s_am[t], sr0 = ma > 16 ? (ma + 1) >> 1 : ma, Kb = s_ao[t] + ma;
-      for (int sp = 0; sp < (ma > 16 ? 2 : 1); ++sp) {
-        const int r0 = sp == 0 ? 0 : sr0, sr = sp == 0 ? sr0 : ma - sr0;
-        SubIt it;
-        it.geo = sr | (r0 << 8); it.Kb = Kb; it.pend = 0; it.pad = 0; it.src = s_apan[t] + (long long)r0 * Kb; it.pad2 = 0;
-        s_it[n] = it;
-        if (n > 0) s_it[n - 1].pend = Kb > 128 ? 2 * RPW : RPW;   // DMA instructions per wave of the following sub-panel
-        ++n;
-      }
+      SubIt it;
+      it.geo = s_am[t]; it.Kb = s_ao[t] + s_am[t]; it.pend = 0; it.pad = 0; it.src = s_apan[t]; it.pad2 = 0;
+      s_it[n++] = it;
     }
     s_nit = n;
   }
@@ -284,69 +278,96 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   d4 tacc[NKT];
 #pragma unroll
   for (int n = 0; n < NKT; ++n) tacc[n] = (d4){0.0, 0.0, 0.0, 0.0};
-  d4 rown = (d4){0.0, 0.0, 0.0, 0.0}, rcross = rown, vprev = rown;   // Schur tiles (jt, jt) and (1, 0); previous V tile
+  d4 rown = (d4){0.0, 0.0, 0.0, 0.0}, rcross = rown, vprevA = rown, vprevB = rown;   // Schur tiles (jt, jt), (1, 0); previous V tiles
   double dacc = 0.0;                                               // leaf units: sum_k V[k][column l15]^2 (this lane's rows)
   int par = 0;
-  bool have_prev = false;
+  bool have_prev = false, prev_wide = false;
 
-  // one sub-panel (sr <= 16 rows of Linv, row length Kb, staged at stg with stride ldS, columns [Kb, Kb+24) zero)
-  auto compute = [&](const double *stg, int sr, int Kb) {
-    if (isref && jt == 0 && two && have_prev) {
-      const double *xp = xch + ((par ^ 1) * NU + u) * 256 + lane;
-      const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
-      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, vprev[0], rcross, 0, 0, 0);
-      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, vprev[1], rcross, 0, 0, 0);
-      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, vprev[2], rcross, 0, 0, 0);
-      rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, vprev[3], rcross, 0, 0, 0);
+#define QMFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0)
+  // the partner wave's V tiles of the previous panel (LDS) against this wave's: Schur tile (1, 0)
+  auto cross_schur = [&]() {
+    const double *xp = xch + ((par ^ 1) * NU + u) * 512 + lane;
+    const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
+    QMFMA(q0, vprevA[0], rcross); QMFMA(q1, vprevA[1], rcross); QMFMA(q2, vprevA[2], rcross); QMFMA(q3, vprevA[3], rcross);
+    if (prev_wide) {
+      const double q4 = xp[256], q5 = xp[320], q6 = xp[384], q7 = xp[448];
+      QMFMA(q4, vprevB[0], rcross); QMFMA(q5, vprevB[1], rcross); QMFMA(q6, vprevB[2], rcross); QMFMA(q7, vprevB[3], rcross);
     }
-    // V = Linv_sub[:, 0:Kb] K[0:Kb, own columns]
+  };
+  // one panel (sr <= 32 rows of Linv, row length Kb, staged at stg with stride ldS, columns [Kb, Kb+24) zero)
+  auto compute = [&](const double *stg, int sr, int Kb) {
+    if (isref && jt == 0 && two && have_prev) cross_schur();
+    const bool wide = sr > 16;
+    // V = Linv[:, 0:Kb] K[0:Kb, own columns]: tile A = rows 0..15, tile B = rows 16..31 (two independent chains).
+    // One loop nest for both panel heights (two separate bodies made the register allocator spill).
     const int ns = (Kb + 3) >> 2;
-    d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 pA = (d4){0.0, 0.0, 0.0, 0.0}, pB = pA;
     {
-      const double *ap = ((l15 < sr) ? stg + (size_t)l15 * ldS : zrow) + l4;
+      const double *apA = ((l15 < sr) ? stg + (size_t)l15 * ldS : zrow) + l4;
+      const double *apB = ((16 + l15 < sr) ? stg + (size_t)(16 + l15) * ldS : zrow) + l4;
 #pragma unroll
       for (int c = 0; c < (NKX + 3) / 4; ++c) {
         if (4 * c < ns) {
-          double a[4];
+          double a[4], b[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] = ap[4 * (4 * c + i)];
+          for (int i = 0; i < 4; ++i) a[i] = apA[4 * (4 * c + i)];
+          if (wide) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = apB[4 * (4 * c + i)];
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            if (4 * c + i < NKX) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], kx[4 * c + i], p, 0, 0, 0);
+            if (4 * c + i < NKX) QMFMA(a[i], kx[4 * c + i], pA);
+          if (wide) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (4 * c + i < NKX) QMFMA(b[i], kx[4 * c + i], pB);
+          }
         }
       }
     }
-    // T[column][chain k] += V_sub' Linv_sub: A = V tile (C layout read as A: contraction over the sub-panel rows)
+    // T[column][chain k] += V' Linv: A = V tiles (C layout read as A: contraction over the panel rows), B from LDS
     {
       const int nst = (sr + 3) >> 2;
       const double *b0 = ((l4 < sr) ? stg + (size_t)l4 * ldS : zrow) + l15;
       const double *b1 = ((4 + l4 < sr) ? stg + (size_t)(4 + l4) * ldS : zrow) + l15;
       const double *b2 = ((8 + l4 < sr) ? stg + (size_t)(8 + l4) * ldS : zrow) + l15;
       const double *b3 = ((12 + l4 < sr) ? stg + (size_t)(12 + l4) * ldS : zrow) + l15;
+      const double *b4 = ((16 + l4 < sr) ? stg + (size_t)(16 + l4) * ldS : zrow) + l15;
+      const double *b5 = ((20 + l4 < sr) ? stg + (size_t)(20 + l4) * ldS : zrow) + l15;
+      const double *b6 = ((24 + l4 < sr) ? stg + (size_t)(24 + l4) * ldS : zrow) + l15;
+      const double *b7 = ((28 + l4 < sr) ? stg + (size_t)(28 + l4) * ldS : zrow) + l15;
 #pragma unroll
       for (int n = 0; n < NKT; ++n) {
         if (n * 16 < Kb) {
           const double x0 = b0[16 * n], x1 = b1[16 * n], x2 = b2[16 * n], x3 = b3[16 * n];
-          tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], x0, tacc[n], 0, 0, 0);
-          if (nst > 1) tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[1], x1, tacc[n], 0, 0, 0);
-          if (nst > 2) tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[2], x2, tacc[n], 0, 0, 0);
-          if (nst > 3) tacc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(p[3], x3, tacc[n], 0, 0, 0);
+          QMFMA(pA[0], x0, tacc[n]);
+          if (nst > 1) QMFMA(pA[1], x1, tacc[n]);
+          if (nst > 2) QMFMA(pA[2], x2, tacc[n]);
+          if (nst > 3) QMFMA(pA[3], x3, tacc[n]);
+          if (wide) {
+            const double x4 = b4[16 * n], x5 = b5[16 * n], x6 = b6[16 * n], x7 = b7[16 * n];
+            QMFMA(pB[0], x4, tacc[n]);
+            if (nst > 5) QMFMA(pB[1], x5, tacc[n]);
+            if (nst > 6) QMFMA(pB[2], x6, tacc[n]);
+            if (nst > 7) QMFMA(pB[3], x7, tacc[n]);
+          }
         }
       }
     }
     if (isref) {
-      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[0], p[0], rown, 0, 0, 0);
-      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[1], p[1], rown, 0, 0, 0);
-      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[2], p[2], rown, 0, 0, 0);
-      rown = __builtin_amdgcn_mfma_f64_16x16x4f64(p[3], p[3], rown, 0, 0, 0);
+      QMFMA(pA[0], pA[0], rown); QMFMA(pA[1], pA[1], rown); QMFMA(pA[2], pA[2], rown); QMFMA(pA[3], pA[3], rown);
+      if (wide) { QMFMA(pB[0], pB[0], rown); QMFMA(pB[1], pB[1], rown); QMFMA(pB[2], pB[2], rown); QMFMA(pB[3], pB[3], rown); }
       if (jt == 1) {
-        double *xp = xch + (par * NU + u) * 256 + lane;
-        xp[0] = p[0]; xp[64] = p[1]; xp[128] = p[2]; xp[192] = p[3];
-      } else vprev = p;
-      have_prev = true;
+        double *xp = xch + (par * NU + u) * 512 + lane;
+        xp[0] = pA[0]; xp[64] = pA[1]; xp[128] = pA[2]; xp[192] = pA[3];
+        if (wide) { xp[256] = pB[0]; xp[320] = pB[1]; xp[384] = pB[2]; xp[448] = pB[3]; }
+      } else { vprevA = pA; vprevB = pB; }
+      have_prev = true; prev_wide = wide;
       par ^= 1;
     } else {
-      dacc += p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
+      dacc += pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2] + pA[3] * pA[3];
+      if (wide) dacc += pB[0] * pB[0] + pB[1] * pB[1] + pB[2] * pB[2] + pB[3] * pB[3];
     }
   };
 
@@ -380,58 +401,43 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   }
 
   STAMP(2);
-  // ---- the shared chain, last ancestor first, in sub-panels of <= 16 rows.  Sub-panels travel from global memory
-  // straight into a ring of LDS buffers (LDS-DMA, no registers): the one after next is requested while the matrix
-  // cores work on the current one; one LDS-only barrier per sub-panel.
+  // ---- the shared chain, last ancestor first, one whole panel (<= 32 rows) per step.  Panels travel from global memory
+  // straight into one of two LDS buffers (LDS-DMA, no registers): the next one is requested when the matrix cores start
+  // on the current one; one LDS-only barrier per panel.
   {
-    constexpr int D = NU >= 3 ? 3 : 2;   // ring depth (the arena holds NU buffers)
+    constexpr int RP = 32 / NW;   // rows per wave
     const int nit = RFL(s_nit);
-    // every wave issues exactly RPW * (Kb > 128 ? 2 : 1) DMA instructions per sub-panel (rows beyond sr re-read row sr-1)
     auto issue = [&](int i, double *buf) {
       const SubIt it = s_it[i];
-      const int sr = RFL(it.geo) & 255, Kb = RFL(it.Kb);
+      const int sr = RFL(it.geo), Kb = RFL(it.Kb);
       const double *base = A.panels + it.src;
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
+      for (int rr = 0; rr < RP; ++rr) {
         const int row = wid + NW * rr;
-        dma_row(base + (size_t)min(row, sr - 1) * Kb, buf + (size_t)row * ldS, Kb, lane, Kb > 128);
+        if (row < sr) dma_row(base + (size_t)row * Kb, buf + (size_t)row * ldS, Kb, lane, true);
       }
     };
-    int iq = 0, slot_q = 0;   // next sub-panel to request and its ring slot
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-      if (iq < nit) { issue(iq, arena + (size_t)slot_q * 16 * ldS); ++iq; slot_q = slot_q + 1 == D ? 0 : slot_q + 1; }
+    if (nit > 0) issue(0, arena);
     int cur = 0;
     for (int i = 0; i < nit; ++i) {
-      const int geo = RFL(s_it[i].geo), Kb = RFL(s_it[i].Kb), pend = (D == 3) ? RFL(s_it[i].pend) : 0;
-      const int sr = geo & 255;
-      double *buf = arena + (size_t)cur * 16 * ldS;
-      // this wave's own requests for the current sub-panel have landed once at most the next sub-panel's remain in flight
-      if (pend == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (pend == RPW) { if (RPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-      else { if (RPW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      const int sr = RFL(s_it[i].geo), Kb = RFL(s_it[i].Kb);
+      double *buf = arena + (size_t)cur * 32 * ldS;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current panel have landed
 #pragma unroll
-      for (int rr = 0; rr < RPW; ++rr)
+      for (int rr = 0; rr < RP; ++rr)
         if (lane < 24) buf[(size_t)(wid + NW * rr) * ldS + Kb + lane] = 0.0;   // also wipes the DMA's odd-Kb overshoot
       STAMP(5);
       lds_barrier();
       STAMP(3);
-      if (iq < nit) { issue(iq, arena + (size_t)slot_q * 16 * ldS); ++iq; slot_q = slot_q + 1 == D ? 0 : slot_q + 1; }
+      if (i + 1 < nit) issue(i + 1, arena + (size_t)(cur ^ 1) * 32 * ldS);
       STAMP(6);
       if (wact) compute(buf, sr, Kb);
       STAMP(4);
-      cur = cur + 1 == D ? 0 : cur + 1;
+      cur ^= 1;
     }
   }
   lds_barrier();
-  if (isref && jt == 0 && two && have_prev) {   // the last sub-panel's off-diagonal Schur update
-    const double *xp = xch + ((par ^ 1) * NU + u) * 256 + lane;
-    const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
-    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q0, vprev[0], rcross, 0, 0, 0);
-    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q1, vprev[1], rcross, 0, 0, 0);
-    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q2, vprev[2], rcross, 0, 0, 0);
-    rcross = __builtin_amdgcn_mfma_f64_16x16x4f64(q3, vprev[3], rcross, 0, 0, 0);
-  }
+  if (isref && jt == 0 && two && have_prev) cross_schur();   // the last panel's off-diagonal Schur update
 
   // ---- hv = T w_pa for this wave's columns (tile rows l4 + 4 r), summed over the 16 chain columns of a tile row
   {

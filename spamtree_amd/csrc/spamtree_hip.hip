@@ -974,409 +974,6 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Phase A, fast path, second generation (same groups, same results as k_factor_mfma up to rounding):
-//   * K_{pa,u} never touches LDS: every wave keeps the B operands of its K-steps (st = kh, kh+2, ...) in registers,
-//     evaluated straight from the coordinates;
-//   * the Schur complement V'V is accumulated on the fly from the V tiles (C layout = A and B operand of that product);
-//   * the freed LDS double-buffers the sub-panel stage: the next sub-panel is fetched during the whole MFMA section of
-//     the current one and stored while nobody reads that buffer -- three barriers per sub-panel instead of four;
-//   * epilogue as before (T^T dump, register-resident elimination, N = -Ri T on the matrix cores).
-// NKX = K-steps per wave held in registers (chain P <= 8 * NKX).
-// ---------------------------------------------------------------------------------------------------------------
-struct Fast2Args {
-  const Blk *blks;
-  const int *anc_idx;
-  const Grp *grps;
-  int ngrp;
-  const double *cx, *cy;
-  const int *mv;
-  const double *w;
-  double *panels;
-  double *logdet_c, *loglik_c;
-  int *errflag;
-  int Pm4, ldKV, ldS, SRm, stg, x_dbl;   // stg: doubles of one stage buffer; x_dbl: region X (2 stage buffers | T^T dump)
-};
-
-template <int NKX>
-__global__ __launch_bounds__(NT, 2) void k_factor_mfma2(Fast2Args A, CovPar cp) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
-  __shared__ int s_fail;
-  __shared__ double s_red[NT / 64];
-  __shared__ long long s_bpan[32], s_brow[32];
-  __shared__ int s_bld[32];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int jt = wid & 1, kh = wid >> 1;
-  const int Pm4 = A.Pm4, ldKV = A.ldKV, ldS = A.ldS, SRm = A.SRm;
-  double *X = lds;                                   // stage[0] | stage[1]   /   T^T dump [k][ldKV]
-  double *Y = X + A.x_dbl;                           // R, Ri (stride CH_LD), elimination scratch
-  double *zrow = Y + 2 * 32 * CH_LD + 216 + 36;      // ldS + 16 zeros
-  double *Vx = zrow + ldS + 16;                      // FM_VPART: V tile exchange, later w_pa
-  double *colx = Vx + FM_VPART, *coly = colx + 32, *colw = coly + 32, *hv = colw + 32, *rd = hv + 32;
-  int *colmv = (int *)(rd + 32);
-  int *colblk = colmv + 32;
-
-  int gidx = blockIdx.x;
-  {
-    const int per = A.ngrp >> 3;
-    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-  }
-  const Grp G = A.grps[gidx];
-  const int M = G.M, P = G.P;
-  const Blk B0 = A.blks[G.blk0];
-  const int J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
-  STAMP_DECL
-  if (tid < J) {
-    const int a = A.anc_idx[B0.anc_ptr + tid];
-    s_am[tid] = A.blks[a].m;
-    s_arow[tid] = A.blks[a].row0;
-    s_apan[tid] = A.blks[a].panel_off;
-  }
-  if (tid >= 64 && tid < 64 + G.nblk) {
-    const Blk Bb = A.blks[G.blk0 + tid - 64];
-    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
-  }
-  if (tid == 0) s_fail = 0;
-  __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-    s_ao[J] = o;
-  }
-  __syncthreads();
-
-  // ---- sub-panel geometry + register prefetch (rows wid, wid+4, .. x 4 chunks of 64 columns)
-  double pre[16];
-  auto sub_geom = [&](int t, int s, int &r0, int &sr, int &Kb) {
-    const int ma = s_am[t];
-    const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
-    r0 = s == 0 ? 0 : sr0;
-    sr = s == 0 ? sr0 : ma - sr0;
-    Kb = s_ao[t] + ma;
-  };
-  auto fetch = [&](int t, int s) {
-    int r0, sr, Kb;
-    sub_geom(t, s, r0, sr, Kb);
-    const double *src = A.panels + s_apan[t] + (size_t)(r0 + wid) * Kb + lane;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-#ifdef FM_NOFETCH
-        pre[rr * 4 + c] = 1e-3;
-#else
-        pre[rr * 4 + c] = (wid + 4 * rr < sr && lane + 64 * c < Kb) ? src[(size_t)(4 * rr) * Kb + 64 * c] : 0.0;
-#endif
-      }
-    }
-  };
-  auto stash = [&](double *stg_, int t, int s) {
-    int r0, sr, Kb;
-    sub_geom(t, s, r0, sr, Kb);
-    double *dst = stg_ + (size_t)wid * ldS + lane;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (wid + 4 * rr < sr && lane + 64 * c < Kb) dst[(size_t)(4 * rr) * ldS + 64 * c] = pre[rr * 4 + c];
-    }
-    if (tid < sr * 4) stg_[(size_t)(tid >> 2) * ldS + Kb + (tid & 3)] = 0.0;   // k in [Kb, Kb+4) reads as zero
-  };
-  int t = J - 1, s = 0;
-  if (t >= 0) fetch(t, s);      // in flight during the covariance evaluation below
-
-  // ---- prologue: coordinates (ancestors alias region X), B operands of this wave's K-steps into registers
-  double kx[NKX];
-  {
-    double *sx = X, *sy = X + Pm4;
-    int *smv = (int *)(X + 2 * (size_t)Pm4);
-    for (int tt = 0; tt < J; ++tt) {
-      const long long r0 = s_arow[tt];
-      const int oa = s_ao[tt];
-      for (int i = tid; i < s_am[tt]; i += NT) { sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; }
-    }
-    if (tid < 32) {
-      const int j = tid;
-      if (j < M) {
-        const long long r = G.row0 + j;
-        colx[j] = A.cx[r]; coly[j] = A.cy[r]; colw[j] = A.w[r]; colmv[j] = A.mv[r];
-        int bi = 0;
-        while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
-        colblk[j] = bi;
-      } else {
-        colx[j] = 0.0; coly[j] = 0.0; colw[j] = 0.0; colmv[j] = 0; colblk[j] = 0;
-      }
-    }
-    for (int k = tid; k < ldS + 16; k += NT) zrow[k] = 0.0;
-    __syncthreads();
-    const int j = jt * 16 + l15;
-    const double xj = colx[j], yj = coly[j];
-    const int mj = colmv[j];
-    // The covariance code is kept as ONE rolled loop (a fully unrolled register fill inlines it NKX times: > 100 KB of
-    // code, which thrashes the instruction cache).  Values pass through a thread-private LDS column behind the
-    // coordinates, half of the K-steps at a time, and are then read back into registers with constant indices.
-    double *tmp = X + 2 * (size_t)Pm4 + (Pm4 >> 1) + 2 + tid;
-    constexpr int HALF = (NKX + 1) / 2;
-#pragma unroll
-    for (int hsel = 0; hsel < 2; ++hsel) {
-#pragma unroll 1
-      for (int uu = 0; uu < HALF; ++uu) {
-        const int u = hsel * HALF + uu;
-        const int k = 4 * (kh + 2 * u) + l4;
-        double v = 0.0;
-        if (u < NKX && k < P && j < M) v = cov_entry(cp, sx[k], sy[k], smv[k], xj, yj, mj);   // only rows that were loaded
-        tmp[(size_t)uu * NT] = v;
-      }
-#pragma unroll
-      for (int uu = 0; uu < HALF; ++uu)
-        if (hsel * HALF + uu < NKX) kx[hsel * HALF + uu] = tmp[(size_t)uu * NT];
-    }
-    __syncthreads();   // coordinates consumed: region X becomes the stage
-  }
-  d4 acc[8];
-#pragma unroll
-  for (int n = 0; n < 8; ++n) acc[n] = (d4){0.0, 0.0, 0.0, 0.0};
-  d4 racc = (d4){0.0, 0.0, 0.0, 0.0};     // Schur tile (rows of column tile kh, columns of column tile jt)
-  STAMP(0);
-  const bool need_r = refgrp ? (kh >= jt && kh * 16 < M && jt * 16 < M) : (kh == jt && jt * 16 < M);
-
-  int cur = 0;
-  if (t >= 0) {
-    stash(X, t, s);
-    int tn = t, sn = s + 1;
-    if (sn >= (s_am[t] > 16 ? 2 : 1)) { tn = t - 1; sn = 0; }
-    if (tn >= 0) fetch(tn, sn);
-  }
-  while (t >= 0) {
-    const int ma = s_am[t];
-    const int nsub = ma > 16 ? 2 : 1;
-    int r0, sr, Kb;
-    sub_geom(t, s, r0, sr, Kb);
-    int tn = t, sn = s + 1;
-    if (sn >= nsub) { tn = t - 1; sn = 0; }
-    double *stg_cur = X + (size_t)cur * A.stg;
-    __syncthreads();                       // stage[cur] visible; Vx free
-    STAMP(1);
-    // ---- V_sub partial: this wave's K-steps, B operands from registers
-    d4 p = (d4){0.0, 0.0, 0.0, 0.0};
-    {
-      const double *ap = ((l15 < sr) ? stg_cur + (size_t)l15 * ldS : zrow) + 4 * kh + l4;
-      const int ns = (Kb + 3) >> 2;
-      const int nu = (ns - kh + 1) >> 1;           // this wave's K-steps st = kh + 2u < ns
-      // chunks of four K-steps: the four LDS reads are issued together; a step past nu contributes a zero A operand
-#pragma unroll
-      for (int c = 0; c < (NKX + 3) / 4; ++c) {
-        if (4 * c < nu) {
-          double a4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int u = 4 * c + e;
-            const double av = ap[8 * (u < NKX ? u : 0)];
-            a4[e] = (u < nu) ? av : 0.0;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int u = 4 * c + e;
-            if (u < NKX) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[e], kx[u], p, 0, 0, 0);
-          }
-        }
-      }
-    }
-    STAMP(2);
-    if (kh == 1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Vx[jt * 256 + r * 64 + lane] = p[r];
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] += Vx[jt * 256 + r * 64 + lane];
-        Vx[jt * 256 + r * 64 + lane] = p[r];
-      }
-    }
-    __syncthreads();
-    if (kh == 1) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[r] = Vx[jt * 256 + r * 64 + lane];
-    }
-    STAMP(3);
-    // ---- Schur tile += V_sub(:, tile kh)' V_sub(:, tile jt): the C layout of a V tile is both operands
-    if (need_r) {
-      d4 q = p;
-      if (kh != jt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) q[r] = Vx[kh * 256 + r * 64 + lane];
-      }
-#pragma unroll
-      for (int st = 0; st < 4; ++st) racc = __builtin_amdgcn_mfma_f64_16x16x4f64(q[st], p[st], racc, 0, 0, 0);
-    }
-    // ---- T^T tiles (kt = kh, kh+2, ...) += Linv_sub^T * V_sub
-    {
-      const int nst = (sr + 3) >> 2;
-      const int kb0 = kh * 16 + l15;
-      const double *r0p = ((l4 < sr) ? stg_cur + (size_t)l4 * ldS : zrow) + kb0;
-      const double *r1p = ((4 + l4 < sr) ? stg_cur + (size_t)(4 + l4) * ldS : zrow) + kb0;
-      const double *r2p = ((8 + l4 < sr) ? stg_cur + (size_t)(8 + l4) * ldS : zrow) + kb0;
-      const double *r3p = ((12 + l4 < sr) ? stg_cur + (size_t)(12 + l4) * ldS : zrow) + kb0;
-#pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        const int kt = kh + 2 * n;
-        if (kt * 16 < Kb) {
-          const bool kok = kb0 + 32 * n < Kb;   // the boundary tile must not touch T columns of later panels
-          double a0 = r0p[32 * n], a1 = r1p[32 * n], a2 = r2p[32 * n], a3 = r3p[32 * n];
-          a0 = kok ? a0 : 0.0; a1 = kok ? a1 : 0.0; a2 = kok ? a2 : 0.0; a3 = kok ? a3 : 0.0;
-          acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, p[0], acc[n], 0, 0, 0);
-          if (nst > 1) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, p[1], acc[n], 0, 0, 0);
-          if (nst > 2) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, p[2], acc[n], 0, 0, 0);
-          if (nst > 3) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, p[3], acc[n], 0, 0, 0);
-        }
-      }
-    }
-    STAMP(4);
-    // ---- the prefetched next sub-panel goes into the other buffer (its last readers finished before the barriers
-    // above), then the one after it is requested
-    if (tn >= 0) {
-      stash(X + (size_t)(cur ^ 1) * A.stg, tn, sn);
-      int t2 = tn, s2 = sn + 1;
-      if (s2 >= (s_am[tn] > 16 ? 2 : 1)) { t2 = tn - 1; s2 = 0; }
-      if (t2 >= 0) fetch(t2, s2);
-    }
-    cur ^= 1;
-    t = tn; s = sn;
-    STAMP(5);
-  }
-  __syncthreads();
-
-  double *KV = X;   // from here on region X holds T^T in the [k][ldKV] layout
-  double *R = Y, *Ri = Y + 32 * CH_LD;
-  double *chcol = Ri + 32 * CH_LD, *chrs = chcol + 216;
-  if (refgrp) {
-    if (need_r) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = kh * 16 + l4 + 4 * r, j = jt * 16 + l15;
-        if (i < M && j < M && j <= i)
-          R[i * CH_LD + j] = cov_entry(cp, colx[i], coly[i], colmv[i], colx[j], coly[j], colmv[j]) - racc[r];
-      }
-    }
-    for (int idx = tid; idx < 32 * CH_LD; idx += NT) Ri[idx] = (idx / CH_LD == idx % CH_LD) ? 1.0 : 0.0;
-  } else {
-    if (need_r) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int il = l4 + 4 * r;                      // diagonal entries of the diagonal tiles
-        if (il == l15 && jt * 16 + l15 < M) {
-          const int j = jt * 16 + l15;
-          const double d = cov_entry(cp, colx[j], coly[j], colmv[j], colx[j], coly[j], colmv[j]) - racc[r];
-          if (!(d > 0.0)) s_fail = 1;
-          rd[j] = 1.0 / sqrt(d);
-        }
-      }
-    }
-  }
-  // ---- dump T^T (pads zero), w_pa
-#pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    const int kt = kh + 2 * n;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = kt * 16 + l4 + 4 * r, j = jt * 16 + l15;
-      if (k < Pm4 && j < ldKV) KV[(size_t)k * ldKV + j] = (k < P && j < M) ? acc[n][r] : 0.0;
-    }
-  }
-  double *wpa = Vx;
-  for (int tt = 0; tt < J; ++tt)
-    for (int i = tid; i < s_am[tt]; i += NT) wpa[s_ao[tt] + i] = A.w[s_arow[tt] + i];
-  __syncthreads();
-  STAMP(7);
-  if (refgrp) block_chol_eliminate(R, Ri, nullptr, M, chcol, chrs, &s_fail);
-  for (int j = wid; j < M; j += NT / 64) {
-    double a = 0.0;
-    for (int k = lane; k < P; k += 64) a += KV[(size_t)k * ldKV + j] * wpa[k];
-    a = wave_sum(a);
-    if (lane == 0) hv[j] = a;
-  }
-  __syncthreads();
-  STAMP(8);
-
-  double wcore_part = 0.0, logdet_part = 0.0;
-  if (refgrp) {
-    double *pu = A.panels + B0.panel_off;
-    const int ld = B0.ld;
-    const int nkt = (P + 15) >> 4, nit = (M + 15) >> 4;
-    for (int tile = wid; tile < nit * nkt; tile += NT / 64) {
-      const int it = tile % nit, kt = tile / nit;
-      const int njs = (min(M, it * 16 + 16) + 3) >> 2;
-      const int i = it * 16 + l15;
-      const int krow = min(kt * 16 + l15, Pm4 - 1);
-      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int st = 0; st < njs; ++st) {
-        const int j = 4 * st + l4;
-        const double a = (i < M && j <= i) ? -Ri[i * CH_LD + j] : 0.0;
-        const double b = KV[(size_t)krow * ldKV + j];
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int io = it * 16 + l4 + 4 * r, k = kt * 16 + l15;
-        if (io < M && k < P) pu[(size_t)io * ld + k] = c[r];
-      }
-    }
-    for (int idx = tid; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      pu[(size_t)i * ld + P + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
-    }
-    if (tid < M) {
-      const int i = tid;
-      double e = 0.0;
-      for (int j = 0; j <= i; ++j) e += Ri[i * CH_LD + j] * (colw[j] - hv[j]);
-      wcore_part = e * e;
-      logdet_part = log(Ri[i * CH_LD + i]);
-    }
-    const double wcore = block_sum(wcore_part, s_red);
-    const double logdet = block_sum(logdet_part, s_red);
-    if (tid == 0) {
-      A.logdet_c[G.blk0] = logdet;
-      A.loglik_c[G.blk0] = (double)M * HL2PI - 0.5 * wcore;
-      if (s_fail) atomicMin(A.errflag, B0.level * 16 + (J == 0 ? 1 : 2));
-    }
-  } else {
-    for (int j = wid; j < M; j += NT / 64) {
-      const int bi = colblk[j];
-      double *prow = A.panels + s_bpan[bi] + (size_t)(G.row0 + j - s_brow[bi]) * s_bld[bi];
-      const double r = rd[j];
-      for (int k = lane; k < P; k += 64) prow[k] = -r * KV[(size_t)k * ldKV + j];
-      if (lane == 0) prow[P] = r;
-    }
-    if (tid < G.nblk) {
-      const int bi = tid;
-      double wc = 0.0, ldt = 0.0;
-      int cnt = 0;
-      for (int j = 0; j < M; ++j)
-        if (colblk[j] == bi) {
-          const double e = rd[j] * (colw[j] - hv[j]);
-          wc += e * e;
-          ldt += log(rd[j]);
-          ++cnt;
-        }
-      A.logdet_c[G.blk0 + bi] = ldt;
-      A.loglik_c[G.blk0 + bi] = (double)cnt * HL2PI - 0.5 * wc;
-    }
-    if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 3);
-  }
-  STAMP(9);
-  STAMP_FLUSH;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase B: block-Gibbs draw of w_u + message push (spamtree_model.cpp:1011-1226), one workgroup per block.
-// ---------------------------------------------------------------------------------------------------------------
 #include "factor_quad.hpp"
 
 struct SampleArgs {
@@ -2033,8 +1630,6 @@ struct LevelInfo {
   size_t lds_fast = 0;
   int ldN = 2, Mr4 = 4;
   size_t lds_sfast = 0;
-  int stg2 = 0, x_dbl2 = 0, nkx2 = 0;                    // k_factor_mfma2 geometry (0 = not eligible)
-  size_t lds_fast2 = 0;
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
   int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
@@ -2499,16 +2094,6 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         ok = L.lds_fast <= h->lds_limit;
       }
       if (ok) {
-        // second-generation kernel: region X = max(two stage buffers, T^T dump, prologue coordinates)
-        L.stg2 = (L.SRm * L.ldS + 16 + 1) & ~1;
-        size_t x = std::max((size_t)2 * L.stg2, (size_t)L.Pm4 * L.ldKV + 16);
-        L.nkx2 = L.Pm4 <= 128 ? 16 : (L.Pm4 <= 208 ? 26 : 32);
-        x = std::max(x, (size_t)2 * L.Pm4 + L.Pm4 / 2 + 2 + (size_t)((L.nkx2 + 1) / 2) * NT + 8);   // prologue: coordinates + covariance pass-through
-        L.x_dbl2 = (int)((x + 1) & ~(size_t)1);
-        L.lds_fast2 = ((size_t)L.x_dbl2 + 2 * 32 * CH_LD + 216 + 36 + L.ldS + 16 + FM_VPART + 5 * 32) * 8 + 64 * 4 + 64;
-        if (L.lds_fast2 > h->lds_limit) L.nkx2 = 0;
-      }
-      if (ok) {
         L.Mr4 = std::max(4, (maxM + 3) & ~3);
         L.ldN = (L.maxLd + 16 + 1) | 1;   // odd stride, room for the 16-wide tile overshoot
         L.ldN = std::max(L.ldN, L.maxP + 33);
@@ -2569,30 +2154,40 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     // (reference levels) or the chain without its last ancestor (leaf levels: cousins)
     L.quad_first = (int)h->quads.size(); L.quad_count = 0; L.q_nkx = 0; L.qown_lo = 0; L.qown_n = 0;
     if (L.fast && L.maxP > 0 && L.maxP <= 200 && L.maxMa <= 32) {
-      int k = 0, qlo = INT_MAX, qhi = 0;
       bool mixed = false;
-      while (k < L.grp_count) {
-        const Grp &G0 = h->grps[L.grp_first + k];
-        const Blk &B0 = h->blks[G0.blk0];
-        const int J = B0.nanc, Jc = B0.isref ? J : std::max(J - 1, 0);
-        if ((B0.isref != 0) != (L.isref != 0)) mixed = true;
-        Quad Qd;
-        Qd.g0 = k; Qd.nu = 1; Qd.Jc = Jc; Qd.Pc = 0;
-        for (int t = 0; t < Jc; ++t) Qd.Pc += h->blks[h->anc_idx[B0.anc_ptr + t]].m;
-        while (Qd.nu < h->quad_nu && k + Qd.nu < L.grp_count) {
-          const Grp &G1 = h->grps[L.grp_first + k + Qd.nu];
-          const Blk &B1 = h->blks[G1.blk0];
-          if (B1.nanc != J || B1.isref != B0.isref || h->blk_owner[G1.blk0] != h->blk_owner[G0.blk0]) break;
-          bool same = true;
-          for (int t = 0; t < Jc && same; ++t) same = h->anc_idx[B1.anc_ptr + t] == h->anc_idx[B0.anc_ptr + t];
-          if (!same) break;
-          ++Qd.nu;
+      int qlo = INT_MAX, qhi = 0;
+      // pass 0 ignores ownership: its quad count decides eligibility, so that every rank of every world size takes
+      // the same kernel for a level (results are then bit-identical across world sizes); pass 1 builds this rank's quads
+      int nq_any = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        int k = 0;
+        while (k < L.grp_count) {
+          const Grp &G0 = h->grps[L.grp_first + k];
+          const Blk &B0 = h->blks[G0.blk0];
+          const int J = B0.nanc, Jc = B0.isref ? J : std::max(J - 1, 0);
+          if ((B0.isref != 0) != (L.isref != 0)) mixed = true;
+          Quad Qd;
+          Qd.g0 = k; Qd.nu = 1; Qd.Jc = Jc; Qd.Pc = 0;
+          for (int t = 0; t < Jc; ++t) Qd.Pc += h->blks[h->anc_idx[B0.anc_ptr + t]].m;
+          while (Qd.nu < h->quad_nu && k + Qd.nu < L.grp_count) {
+            const Grp &G1 = h->grps[L.grp_first + k + Qd.nu];
+            const Blk &B1 = h->blks[G1.blk0];
+            if (B1.nanc != J || B1.isref != B0.isref) break;
+            if (pass == 1 && h->blk_owner[G1.blk0] != h->blk_owner[G0.blk0]) break;
+            bool same = true;
+            for (int t = 0; t < Jc && same; ++t) same = h->anc_idx[B1.anc_ptr + t] == h->anc_idx[B0.anc_ptr + t];
+            if (!same) break;
+            ++Qd.nu;
+          }
+          if (pass == 0) ++nq_any;
+          else {
+            const bool mine = g < h->cut || h->blk_owner[G0.blk0] == h->rank;
+            if (mine) { qlo = std::min(qlo, L.quad_count); qhi = std::max(qhi, L.quad_count + 1); }
+            h->quads.push_back(Qd);
+            L.quad_count++;
+          }
+          k += Qd.nu;
         }
-        const bool mine = g < h->cut || h->blk_owner[G0.blk0] == h->rank;
-        if (mine) { qlo = std::min(qlo, L.quad_count); qhi = std::max(qhi, L.quad_count + 1); }
-        h->quads.push_back(Qd);
-        L.quad_count++;
-        k += Qd.nu;
       }
       L.qown_lo = qlo < qhi ? qlo : 0; L.qown_n = qlo < qhi ? qhi - qlo : 0;
       const int need = (L.maxP + 3) / 4;
@@ -2600,8 +2195,10 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       int ldS = std::max(std::max(L.maxP + 24, 4 * L.q_nkx + 4), 178);
       while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
       L.q_ldS = ldS;
-      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)2 * h->quad_nu * 256 : 0)) * 8;
-      if (L.grp_count < 2 * L.quad_count || mixed) L.q_nkx = 0;   // mostly singletons: nothing to share
+      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)2 * h->quad_nu * 512 : 0)) * 8;
+      int min_groups = 2 * h->sm_count;   // smaller levels do not fill the chip with quads: k_factor_mfma's 4x more workgroups win
+      { const char *e = getenv("SPAMTREE_QUAD_MIN"); if (e) min_groups = atoi(e); }
+      if (L.grp_count < 2 * nq_any || mixed || L.grp_count < min_groups) L.q_nkx = 0;   // mostly singletons: nothing to share
       if (L.isref && L.q_nkx == 50) L.q_nkx = 0;                   // that instantiation spills registers: k_factor_mfma is faster
     }
   }
@@ -2736,15 +2333,11 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute((const void *)k_factor_mfma2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute((const void *)k_factor_mfma2<26>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute((const void *)k_factor_mfma2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
-    // 1 (default) = k_factor_mfma; 2 = k_factor_mfma2 (register-resident K operand, on-the-fly Schur complement,
-    // double-buffered stage): same results, same speed on MI355X today, kept as the base of the
-    // wave-specialised version
+    // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
+    // chains <= 200 rows, LDS fits) and k_factor_mfma elsewhere; 1 = k_factor_mfma everywhere
     const char *e = getenv("SPAMTREE_FACTOR_KERNEL");
-    h->factor_gen = (e && e[0] == '2') ? 2 : ((e && e[0] == '3') ? 3 : 1);
+    h->factor_gen = (e && e[0] == '1') ? 1 : 3;
   }
   {
     // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
@@ -2758,9 +2351,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     }
     for (auto &L : h->levels) {
       if (L.q_nkx == 0) continue;
-      int minq = h->sm_count / 2;
-      { const char *e = getenv("SPAMTREE_QUAD_MIN"); if (e) minq = atoi(e); }
-      if (L.lds_quad + stat > 160 * 1024 || L.qown_n < minq) L.q_nkx = 0;
+      if (L.lds_quad + stat > 160 * 1024) L.q_nkx = 0;
     }
 #define QATTR(NU_, NKX_, NKT_)                                                                                                       \
   (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
@@ -2961,16 +2552,6 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
   } while (0)
         if (L.q_nkx == 32) QLAUNCH(4, 32, 8); else if (L.q_nkx == 38) QLAUNCH(4, 38, 10); else if (L.q_nkx == 44) QLAUNCH(4, 44, 11); else QLAUNCH(4, 50, 13);
 #undef QLAUNCH
-      } else if (L.fast && h->factor_gen == 2 && L.nkx2 > 0) {
-        Fast2Args F;
-        std::memset(&F, 0, sizeof(F));
-        F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
-        F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
-        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p;
-        F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stg = L.stg2; F.x_dbl = L.x_dbl2;
-        if (L.nkx2 == 16) hipLaunchKernelGGL(k_factor_mfma2<16>, dim3(L.gown_n), dim3(NT), L.lds_fast2, h->stream, F, cp);
-        else if (L.nkx2 == 26) hipLaunchKernelGGL(k_factor_mfma2<26>, dim3(L.gown_n), dim3(NT), L.lds_fast2, h->stream, F, cp);
-        else hipLaunchKernelGGL(k_factor_mfma2<32>, dim3(L.gown_n), dim3(NT), L.lds_fast2, h->stream, F, cp);
       } else if (L.fast) {
         FastArgs F;
         std::memset(&F, 0, sizeof(F));

@@ -16,8 +16,12 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("side,q", [(120, 1), (48, 3)])
-def test_sharded_equals_single_process_bitwise(side, q, tmp_path):
+@pytest.mark.parametrize("side,q,quad_min", [(120, 1, None), (48, 3, None), (120, 1, "1")])
+def test_sharded_equals_single_process_bitwise(side, q, quad_min, tmp_path, monkeypatch):
+    """quad_min = "1": even these small levels take k_factor_quad (SPAMTREE_QUAD_MIN, inherited by the spawned ranks),
+    whose quads are cut at ownership boundaries -- the results must not depend on how they are cut."""
+    if quad_min:
+        monkeypatch.setenv("SPAMTREE_QUAD_MIN", quad_min)
     import torch.multiprocessing as mp
     from tests._sharded_worker import gpu_worker
     steps = 2
