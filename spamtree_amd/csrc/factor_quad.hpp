@@ -37,19 +37,28 @@ struct QuadArgs {
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
 };
 
-// Team version of block_chol_eliminate: the workgroup is split into teams of 128 threads, each team eliminates its own
-// m x m matrix ([A | I] -> [L | L^{-1}]); all teams run the same pivot loop (mmax = largest m, uniform) and share its
-// barrier.  A: LDS, row stride CH_LD, lower triangle valid; Bm receives L^{-1} (lower); pub: 216 doubles per team.
-template <int TCH_EPT>
+// Team elimination [A | I] -> [. | L^{-1}] of an m x m SPD matrix (m <= 32): the workgroup is split into teams of 128
+// threads, one matrix each; all teams run the same pivot loop (mmax = largest m, uniform) and share its barrier.
+// Every thread keeps EPT elements of the lower triangles of A and of B = I in registers (m (m + 1) <= 128 EPT).
+// Per pivot k the team publishes, UNSCALED, column k of A strictly below the diagonal, the pivot d_k itself, and row k
+// of B; everything outside those ranges reads as zero, so the update is the same two instructions for every element
+// at every pivot -- val -= (x1 x2) / d_k with x1 = A[i][k], x2 = A[j][k] or B[k][j] -- with no range tests; rows are
+// scaled by 1 / sqrt(d_i) once at the end.
+//   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).
+//   pub: 224 doubles per team: 2 x 96 published cells ([0,36) column, [36,72) row, [80] pivot, [95] always zero), rsd[32]
+template <int EPT>
 __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
   const int nA = m * (m + 1) / 2, nE = 2 * nA;
-  lds_barrier();
-  int o1[TCH_EPT], o2[TCH_EPT], klo[TCH_EPT], khi[TCH_EPT], opub[TCH_EPT], eoff[TCH_EPT];
-  double val[TCH_EPT];
+  double *rsd = pub + 192;
+  for (int i = ttid; i < 192; i += 128) pub[i] = 0.0;
+  lds_barrier();   // Am was written by other threads; pub is zero
+  unsigned pk[EPT];   // o1 [0,7) | o2 [7,14) | khi [14,20) | opub [20,27)
+  int eoff[EPT];      // B elements: offset into Bm, else -1
+  double val[EPT];
 #pragma unroll
-  for (int r = 0; r < TCH_EPT; ++r) {
+  for (int r = 0; r < EPT; ++r) {
     const int e = ttid + 128 * r;
-    o1[r] = 0; o2[r] = 0; klo[r] = 0; khi[r] = -1; opub[r] = 0; eoff[r] = -1; val[r] = 0.0;
+    pk[r] = 95u | (95u << 7) | (63u << 14) | (95u << 20); eoff[r] = -1; val[r] = 0.0;
     if (e < nE) {
       const int t = e < nA ? 0 : 1;
       const int f = e - t * nA;
@@ -57,41 +66,37 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
       while (i * (i + 1) / 2 > f) --i;
       while ((i + 1) * (i + 2) / 2 <= f) ++i;
       const int j = f - i * (i + 1) / 2;
-      o1[r] = i;
-      o2[r] = t == 0 ? j : 36 + j;
-      klo[r] = t == 1 ? j : 0;
-      khi[r] = t == 0 ? j : i;        // rank-1 updates while klo <= k < khi, scaling and publication at k == khi
-      opub[r] = t == 0 ? i : 36 + j;
-      eoff[r] = (t == 0 ? 0 : 1) * 65536 + i * CH_LD + j;
+      const unsigned o1 = i, o2 = t == 0 ? j : 36 + j, khi = t == 0 ? j : i;
+      const unsigned opub = t == 0 ? (i == j ? 80 : i) : 36 + j;
+      pk[r] = o1 | (o2 << 7) | (khi << 14) | (opub << 20);
+      eoff[r] = t == 1 ? i * CH_LD + j : -1;
       val[r] = t == 0 ? Am[i * CH_LD + j] : (i == j ? 1.0 : 0.0);
     }
   }
   for (int k = 0; k < mmax; ++k) {
-    double *pa = pub + (k & 1) * 108;   // [0,36): column k of A   [36,72): row k of B   (unscaled)
+    double *pa = pub + (k & 1) * 96;
 #pragma unroll
-    for (int r = 0; r < TCH_EPT; ++r)
-      if (k == khi[r]) pa[opub[r]] = val[r];
+    for (int r = 0; r < EPT; ++r)
+      if ((unsigned)k == ((pk[r] >> 14) & 63u)) pa[(pk[r] >> 20) & 127u] = val[r];
+    if (ttid == 0) { pa[k] = 0.0; if (k > 0) pa[k - 1] = 0.0; }   // rows <= k of the column cells hold older pivots' data
     lds_barrier();
     if (k < m) {
-      const double d = pa[k];
-      double x1[TCH_EPT], x2[TCH_EPT];
+      const double d = pa[80];
+      if (ttid == 0) { if (!(d > 0.0)) *fail = 1; rsd[k] = rsqrt(d); }
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
 #pragma unroll
-      for (int r = 0; r < TCH_EPT; ++r) { x1[r] = pa[o1[r]]; x2[r] = pa[o2[r]]; }
-      if (!(d > 0.0) && ttid == 0) *fail = 1;
-      const double rs = rsqrt(d);
-#pragma unroll
-      for (int r = 0; r < TCH_EPT; ++r) {
-        const double vu = val[r] - (x1[r] * rs) * (x2[r] * rs);
-        const double vs = val[r] * rs;
-        val[r] = (k >= klo[r] && k < khi[r]) ? vu : ((k == khi[r]) ? vs : val[r]);
+      for (int r = 0; r < EPT; ++r) {
+        const double x1 = pa[pk[r] & 127u], x2 = pa[(pk[r] >> 7) & 127u];
+        val[r] = fma(-(x1 * x2), rd, val[r]);
       }
     }
   }
+  lds_barrier();   // rsd complete
 #pragma unroll
-  for (int r = 0; r < TCH_EPT; ++r) {
-    if (eoff[r] >= 65536) Bm[eoff[r] - 65536] = val[r];
-    else if (eoff[r] >= 0) Am[eoff[r]] = val[r];
-  }
+  for (int r = 0; r < EPT; ++r)
+    if (eoff[r] >= 0) Bm[eoff[r]] = val[r] * rsd[(pk[r] >> 14) & 63u];
   lds_barrier();
 }
 
@@ -120,12 +125,12 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
   __shared__ int s_uM[NU], s_uP[NU], s_ublk0[NU], s_unblk[NU], s_uref[NU], s_uJ[NU], s_pm[NU], s_fail[NU], s_level;
   __shared__ long long s_urow0[NU], s_prow[NU], s_ppan[NU];
-  constexpr int NB = ISREF ? 1 : 32, NUL = ISREF ? 1 : NU, NUR = ISREF ? NU : 1;   // leaf-only / reference-only arrays
+  constexpr int NB = ISREF ? 1 : 32, NUL = ISREF ? 1 : NU;   // leaf-only arrays
   __shared__ long long s_bpan[NU][NB], s_brow[NU][NB];
   __shared__ int s_bld[NU][NB];
   __shared__ double s_colx[NU][32], s_coly[NU][32], s_colw[NU][32], s_hv[NU][32];
-  __shared__ double s_rd[NUL][32], s_px[NUL][32], s_py[NUL][32], s_pw[NUL][32];
-  __shared__ double s_e2[NUR][32], s_lg[NUR][32];
+  __shared__ double s_px[NUL][32], s_py[NUL][32], s_pw[NUL][32];
+  __shared__ double s_e2[NU][32], s_lg[NU][32];
   __shared__ int s_colmv[NU][32], s_colblk[NUL][32], s_pmv[NUL][32];
   struct SubIt { int geo, Kb, pend, pad; long long src, pad2; };   // one staged panel of the shared chain: geo = rows
   __shared__ SubIt s_it[MAXJ];
@@ -249,19 +254,34 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     for (int hpass = 0; hpass < 2; ++hpass) {
       const int st0 = hpass * KH;
       if (4 * st0 < Pu) {
+        if (cp.q == 1) {   // cexpcov, constants hoisted
+          const double s2 = cp.ai1[0], nphi = -cp.tmv[0];
 #pragma unroll 1
-        for (int i = 0; i < KH; ++i) {
-          const int k = 4 * (st0 + i) + l4;
-          double v = 0.0;
-          if (cok && k < Pu) {
-            double ax, ay; int av;
-            ax = s_sx[min(k, PMAX - 1)]; ay = s_sy[min(k, PMAX - 1)]; av = s_smv[min(k, PMAX - 1)];
+          for (int i = 0; i < KH; ++i) {
+            const int k = 4 * (st0 + i) + l4;
+            double ax = s_sx[min(k, PMAX - 1)], ay = s_sy[min(k, PMAX - 1)];
             if constexpr (!ISREF) {
-              if (k >= Pc) { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
+              if (k >= Pc) { ax = s_px[u][(k - Pc) & 31]; ay = s_py[u][(k - Pc) & 31]; }
             }
-            v = cov_entry(cp, ax, ay, av, mx, my, mvj);
+            const double dx = ax - mx, dy = ay - my;
+            const double v = s2 * cov_exp(nphi * cov_sqrt(fma(dx, dx, dy * dy)));
+            kb[i * 64] = (cok && k < Pu) ? v : 0.0;
           }
-          kb[i * 64] = v;
+        } else {
+#pragma unroll 1
+          for (int i = 0; i < KH; ++i) {
+            const int k = 4 * (st0 + i) + l4;
+            double v = 0.0;
+            if (cok && k < Pu) {
+              double ax, ay; int av;
+              ax = s_sx[min(k, PMAX - 1)]; ay = s_sy[min(k, PMAX - 1)]; av = s_smv[min(k, PMAX - 1)];
+              if constexpr (!ISREF) {
+                if (k >= Pc) { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
+              }
+              v = cov_entry(cp, ax, ay, av, mx, my, mvj);
+            }
+            kb[i * 64] = v;
+          }
         }
 #pragma unroll
         for (int i = 0; i < KH; ++i)
@@ -440,8 +460,8 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   if (isref && jt == 0 && two && have_prev) cross_schur();   // the last panel's off-diagonal Schur update
 
   // ---- hv = T w_pa for this wave's columns (tile rows l4 + 4 r), summed over the 16 chain columns of a tile row
+  double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
   {
-    double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
 #pragma unroll
     for (int n = 0; n < NKT; ++n) {
       const int k = n * 16 + l15;
@@ -474,7 +494,17 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       const double d = cov_entry(cp, s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc], s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc]) - dsum;
       if (!(d > 0.0)) s_fail[u] = 1;
       rj = 1.0 / sqrt(d);
-      if (l4 == 0) s_rd[u][jc] = rj;
+    }
+    {
+      // hv of column l15 sits in h_{l15 >> 2} of the lanes with l4 == (l15 & 3)
+      const int srcl = ((l15 & 3) << 4) | l15;
+      const double t0 = __shfl(h0, srcl, 64), t1 = __shfl(h1, srcl, 64), t2 = __shfl(h2, srcl, 64), t3 = __shfl(h3, srcl, 64);
+      const double hvc = (l15 >> 2) == 0 ? t0 : ((l15 >> 2) == 1 ? t1 : ((l15 >> 2) == 2 ? t2 : t3));
+      if (jc < Mu && l4 == 0) {
+        const double e = rj * (s_colw[u][jc] - hvc);
+        s_e2[u][jc] = e * e;
+        s_lg[u][jc] = log(rj);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -508,6 +538,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   STAMP(11);
   if constexpr (ISREF) {
     // element slots per thread: m (m + 1) <= 128 * slots
+    // element slots per thread: m (m + 1) <= 128 * slots.  (One wave per unit without barriers was tried: slower.)
     if (Mmax <= 27) team_chol_eliminate<6>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
     else team_chol_eliminate<9>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
     STAMP(7);
@@ -606,12 +637,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       double wc = 0.0, ldt = 0.0;
       int cnt = 0;
       for (int j = 0; j < Mu; ++j)
-        if (s_colblk[u][j] == bi) {
-          const double e = s_rd[u][j] * (s_colw[u][j] - s_hv[u][j]);
-          wc += e * e;
-          ldt += log(s_rd[u][j]);
-          ++cnt;
-        }
+        if (s_colblk[u][j] == bi) { wc += s_e2[u][j]; ldt += s_lg[u][j]; ++cnt; }
       A.logdet_c[s_ublk0[u] + bi] = ldt;
       A.loglik_c[s_ublk0[u] + bi] = (double)cnt * HL2PI - 0.5 * wc;
     }

@@ -58,34 +58,46 @@ struct Blk {
 // ---------------------------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------------------------
-// exp(x) for the covariance kernels: two-step Cody-Waite reduction to |r| <= ln2/2, degree-13 Taylor polynomial
-// (truncation error < 5e-18), v_ldexp_f64 for the scaling (overflow -> inf, underflow -> denormals / 0 as in libm).
-// About half the instructions of the library routine; relative error < 2e-16.
+// exp(x) for the covariance kernels: two-step Cody-Waite reduction to |r| <= ln2/2, degree-13 Taylor polynomial in
+// Estrin form (truncation error < 5e-18; short dependency chains, no register copies), v_ldexp_f64 for the scaling
+// (overflow -> inf, underflow -> denormals / 0 as in libm).  Under half the instructions of the library routine;
+// relative error < 3e-16.
 __device__ __forceinline__ double cov_exp(double x) {
+  x = fmax(x, -1500.0);
   const double t = __builtin_rint(x * 1.44269504088896338700e+00);
   double r = fma(t, -6.93147180369123816490e-01, x);
   r = fma(t, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;            // 1/13!
-  p = fma(p, r, 2.0876756987868100e-09);        // 1/12!
-  p = fma(p, r, 2.5052108385441720e-08);        // 1/11!
-  p = fma(p, r, 2.7557319223985893e-07);        // 1/10!
-  p = fma(p, r, 2.7557319223985888e-06);        // 1/9!
-  p = fma(p, r, 2.4801587301587302e-05);        // 1/8!
-  p = fma(p, r, 1.9841269841269841e-04);        // 1/7!
-  p = fma(p, r, 1.3888888888888889e-03);        // 1/6!
-  p = fma(p, r, 8.3333333333333332e-03);        // 1/5!
-  p = fma(p, r, 4.1666666666666664e-02);        // 1/4!
-  p = fma(p, r, 1.6666666666666666e-01);        // 1/3!
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  const double tc = fmin(fmax(t, -2000.0), 2000.0);
-  return __builtin_ldexp(p, (int)tc);
+  const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+  const double a0 = 1.0 + r;
+  const double a1 = fma(1.6666666666666666e-01, r, 0.5);                         // 1/3!, 1/2!
+  const double a2 = fma(8.3333333333333332e-03, r, 4.1666666666666664e-02);      // 1/5!, 1/4!
+  const double a3 = fma(1.9841269841269841e-04, r, 1.3888888888888889e-03);      // 1/7!, 1/6!
+  const double a4 = fma(2.7557319223985893e-06, r, 2.4801587301587302e-05);      // 1/9!, 1/8!
+  const double a5 = fma(2.5052108385441720e-08, r, 2.7557319223985888e-07);      // 1/11!, 1/10!
+  const double a6 = fma(1.6059043836821613e-10, r, 2.0876756987868100e-09);      // 1/13!, 1/12!
+  const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2), b2 = fma(a5, r2, a4);
+  const double d0 = fma(b1, r4, b0), d1 = fma(a6, r4, b2);
+  const double p = fma(d1, r8, d0);
+  return __builtin_ldexp(p, (int)t);   // |t| < 2^31 after the clamp above, or +huge -> saturating conversion -> inf
+}
+
+// sqrt(a) for squared distances: v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections (the library's
+// scheme without its range scaling; correctly rounded in the range taken here); anything else goes to the library.
+__device__ __forceinline__ double cov_sqrt(double a) {
+  if (!(a > 1e-280 && a < 1e280)) return sqrt(a);   // 0 (coincident points), denormal-small, huge, NaN
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  double d = fma(-g, g, a);
+  g = fma(d, h, g);
+  d = fma(-g, g, a);
+  return fma(d, h, g);
 }
 
 __device__ __forceinline__ double cov_entry(const CovPar &c, double xi, double yi, int vi, double xj, double yj, int vj) {
   const double dx = xi - xj, dy = yi - yj;
-  const double h = sqrt(dx * dx + dy * dy);
+  const double h = cov_sqrt(dx * dx + dy * dy);
   if (c.q == 1) return c.ai1[0] * cov_exp(-c.tmv[0] * h);  // cexpcov: sigmasq = ai1(0), phi = thetamv(0)
   const double v = c.D[vi * c.q + vj];
   double cb;  // C_base(h, 0, v)
