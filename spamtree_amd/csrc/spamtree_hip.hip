@@ -1506,6 +1506,101 @@ __global__ __launch_bounds__(NT) void k_loglik(LoglikArgs A) {
   }
 }
 
+// Phase C for the column-group levels: one workgroup per group (a reference block, or <= 32 rows of sibling leaf blocks
+// which share their ancestors' w).  Every wave requests all of its panel rows before the first use (up to 8 rows x 5
+// pieces of 64 columns in flight per lane); a row of the panel is [ N_i | Ri_i 0 ] (reference) or [ N_i | r_i ] (leaf), so
+// the residual e_i = Ri (w_u - H w_pa) is one dot product of the row with [ w_pa ; w_u ].
+struct LoglikGrpArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const Grp *grps;
+  const int *list;   // group indices
+  int nlist;
+  const double *panels;
+  const double *w;
+  double *loglik_c;
+  int maxP;
+};
+
+__global__ __launch_bounds__(NT) void k_loglik_grp(LoglikGrpArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ];
+  __shared__ long long s_bpan[32], s_brow[32];
+  __shared__ int s_bld[32], s_cb[32];
+  __shared__ double s_e2[32];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *wv = lds;   // maxP + 32
+  const Grp G = A.grps[A.list[blockIdx.x]];
+  const int M = G.M, P = G.P;
+  const Blk B0 = A.blks[G.blk0];
+  const int J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid < J) {
+    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + tid]];
+    s_am[tid] = Ba.m; s_arow[tid] = Ba.row0;
+  }
+  if (tid >= 64 && tid < 64 + G.nblk) {
+    const Blk Bb = A.blks[G.blk0 + tid - 64];
+    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
+  }
+  if (tid >= 128 && tid < 128 + 32) wv[P + tid - 128] = (tid - 128 < M) ? A.w[G.row0 + tid - 128] : 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+    s_ao[J] = o;
+  }
+  if (tid >= 64 && tid < 96) {
+    const int j = tid - 64;
+    int bi = 0;
+    if (j < M) { const long long r = G.row0 + j; while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi; }
+    s_cb[j] = bi;
+  }
+  __syncthreads();
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+  }
+  // this wave's rows wid, wid + 4, ...: every load is issued before the first LDS read of w
+  const int rowlen = P + (refgrp ? M : 1);
+  double v[8][5];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int j = wid + 4 * rr, jc = min(j, M - 1);
+    const int bi = s_cb[jc];
+    const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int k = lane + 64 * c;
+      v[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int j = wid + 4 * rr;
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int k = lane + 64 * c;
+      const double wk = k < P ? wv[k] : (refgrp ? (k < rowlen ? wv[k] : 0.0) : wv[P + min(j, 31)]);
+      acc += v[rr][c] * wk;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && j < 32) s_e2[j] = acc * acc;
+  }
+  __syncthreads();
+  if (tid < G.nblk) {
+    double wc = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < M; ++j)
+      if (s_cb[j] == tid) { wc += s_e2[j]; ++cnt; }
+    A.loglik_c[G.blk0 + tid] = (double)cnt * HL2PI - 0.5 * wc;
+  }
+}
+
 // fixed-shape deterministic sums of two arrays: out[0] = sum a, out[1] = sum b.  Stage 1: SUM2_WG workgroups, each a
 // contiguous chunk (thread-strided partial sums, LDS tree); stage 2: one wave adds the SUM2_WG partials in order.
 #define SUM2_WG 64
@@ -1672,6 +1767,8 @@ struct st_handle_s {
   std::vector<int> blk_owner;                 // device block -> owning rank, -1 = replicated
   std::vector<int> own_obs_list;              // observed blocks this rank evaluates in phase C
   DevBuf<int> d_ownobs;
+  std::vector<int> own_grp_list, own_obs_slow; // the same set split: column groups of the fast levels / blocks of the others
+  DevBuf<int> d_owngrp, d_ownslow;
   DevBuf<unsigned char> d_rowmask, d_blkmask; // 1 = this rank contributes the entry to a sum-with-zeros exchange
   DevBuf<double> d_comm;                      // 2*n_blocks + 64 doubles
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
@@ -1794,7 +1891,7 @@ extern "C" int st_destroy(st_handle h) {
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
   h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free();
-  h->d_ownobs.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
+  h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -2298,6 +2395,13 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
   { std::vector<int> a = h->own_obs_list; if (a.empty()) a.push_back(0); CCHK(h->d_ownobs.upload(a)); }
+  for (int g = 0; g < n_actual; ++g) {
+    const LevelInfo &L = h->levels[g];
+    if (L.fast) for (int k = 0; k < L.gown_n; ++k) h->own_grp_list.push_back(L.grp_first + L.gown_lo + k);
+  }
+  for (int b : h->own_obs_list) if (!h->levels[h->blks[b].level].fast) h->own_obs_slow.push_back(b);
+  { std::vector<int> a = h->own_grp_list; if (a.empty()) a.push_back(0); CCHK(h->d_owngrp.upload(a)); }
+  { std::vector<int> a = h->own_obs_slow; if (a.empty()) a.push_back(0); CCHK(h->d_ownslow.upload(a)); }
   CCHK(h->d_rowmask.upload(rowmask)); CCHK(h->d_blkmask.upload(blkmask));
   CCHK(h->d_comm.alloc((size_t)2 * nb + 64));
   CCHK(h->d_w.alloc(n)); CCHK(h->d_xb.alloc(n)); CCHK(h->d_z.alloc(n)); CCHK(h->d_tmp_n.alloc(n + 64));
@@ -2373,8 +2477,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   }
   (void)hipGetLastError();
 #undef CCHK
-  h->prof_level_ms.assign(n_actual, 0.0);
-  h->prof_level_n.assign(n_actual, 0);
+  h->prof_level_ms.assign(2 * n_actual, 0.0);
+  h->prof_level_n.assign(2 * n_actual, 0);
   *out = h;
   return ST_OK;
 }
@@ -2707,7 +2811,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
     A.do_gram = (h->gram_valid && h->cache_gram) ? 0 : 1;
     {
-      ProfScope ps(h, 1);
+      ProfScope ps(h, 1, h->n_actual_groups + g);   // per-level slots of phase B follow those of phase A
       if (L.fast) {
         SampleFastArgs F;
         std::memset(&F, 0, sizeof(F));
@@ -2817,11 +2921,17 @@ extern "C" int st_loglik_local(st_handle h, int slot) {
   for (auto &L : h->levels) { maxP = std::max(maxP, L.maxP); maxM = std::max(maxM, L.maxM); }
   const size_t lds = lds_loglik_bytes(maxP, maxM);
   LoglikArgs A;
-  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_ownobs.p; A.nlist = (int)h->own_obs_list.size();
+  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_ownslow.p; A.nlist = (int)h->own_obs_slow.size();
   A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.loglik_c = h->d_loglik[phys].p; A.maxP = maxP; A.maxM = maxM;
-  if (A.nlist > 0) {
+  {
     ProfScope ps(h, 2);
-    hipLaunchKernelGGL(k_loglik, dim3(A.nlist), dim3(NT), lds, h->stream, A);
+    if (A.nlist > 0) hipLaunchKernelGGL(k_loglik, dim3(A.nlist), dim3(NT), lds, h->stream, A);
+    if (!h->own_grp_list.empty()) {
+      LoglikGrpArgs Gr;
+      Gr.blks = h->d_blks.p; Gr.anc_idx = h->d_anc.p; Gr.grps = h->d_grps.p; Gr.list = h->d_owngrp.p; Gr.nlist = (int)h->own_grp_list.size();
+      Gr.panels = h->d_panels[phys].p; Gr.w = h->d_w.p; Gr.loglik_c = h->d_loglik[phys].p; Gr.maxP = maxP;
+      hipLaunchKernelGGL(k_loglik_grp, dim3(Gr.nlist), dim3(NT), (size_t)(maxP + 32) * sizeof(double), h->stream, Gr);
+    }
   }
   HCHK(h, hipGetLastError());
   HCHK(h, reset_err(h) == ST_OK ? hipSuccess : hipErrorUnknown);
@@ -3001,9 +3111,11 @@ extern "C" int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_l
   HCHK(h, hipSetDevice(h->device));
   prof_harvest(h);
   *n_levels = h->n_actual_groups;
-  for (int g = 0; g < h->n_actual_groups && g < cap; ++g) {
+  // entries [0, n_levels): phase A; when cap >= 2 n_levels, entries [n_levels, 2 n_levels): phase B (k_sample*)
+  const int ng = h->n_actual_groups;
+  for (int g = 0; g < 2 * ng && g < cap; ++g) {
     if (ms_by_level) ms_by_level[g] = h->prof_level_n[g] ? h->prof_level_ms[g] / (double)h->prof_level_n[g] : 0.0;  // mean per launch
-    if (bytes_by_level) bytes_by_level[g] = h->levels[g].alg_bytes_A;
+    if (bytes_by_level) bytes_by_level[g] = g < ng ? h->levels[g].alg_bytes_A : h->levels[g - ng].alg_bytes_B + h->levels[g - ng].alg_bytes_msg;
     h->prof_level_ms[g] = 0.0; h->prof_level_n[g] = 0;
   }
   return ST_OK;

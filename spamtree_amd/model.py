@@ -269,5 +269,13 @@ class SpamTreeMV:
         self._check(self.lib.st_profile_levels(self.h, C.byref(nl), _dp(ms), _dp(by), 64))
         return ms[: nl.value].copy(), by[: nl.value].copy()
 
+    def profile_levels_sample(self):
+        """Mean k_sample* launch time per level (ms) since the last call."""
+        nl = C.c_int32()
+        ms = np.zeros(128)
+        by = np.zeros(128)
+        self._check(self.lib.st_profile_levels(self.h, C.byref(nl), _dp(ms), _dp(by), 128))
+        return ms[nl.value: 2 * nl.value].copy(), by[nl.value: 2 * nl.value].copy()
+
     def synchronize(self):
         self._check(self.lib.st_synchronize(self.h))
