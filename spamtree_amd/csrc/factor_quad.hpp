@@ -37,27 +37,27 @@ struct QuadArgs {
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
 };
 
-// Team elimination [A | I] -> [. | L^{-1}] of an m x m SPD matrix (m <= 32): the workgroup is split into teams of 128
-// threads, one matrix each; all teams run the same pivot loop (mmax = largest m, uniform) and share its barrier.
-// Every thread keeps EPT elements of the lower triangles of A and of B = I in registers (m (m + 1) <= 128 EPT).
+// Team elimination [A | I] -> [. | L^{-1}] of an m x m SPD matrix (m <= 32): the workgroup is split into teams of TEAM
+// threads (128, or the whole workgroup), one matrix each; all teams run the same pivot loop (mmax = largest m, uniform) and share its barrier.
+// Every thread keeps EPT elements of the lower triangles of A and of B = I in registers (m (m + 1) <= TEAM * EPT).
 // Per pivot k the team publishes, UNSCALED, column k of A strictly below the diagonal, the pivot d_k itself, and row k
 // of B; everything outside those ranges reads as zero, so the update is the same two instructions for every element
 // at every pivot -- val -= (x1 x2) / d_k with x1 = A[i][k], x2 = A[j][k] or B[k][j] -- with no range tests; rows are
 // scaled by 1 / sqrt(d_i) once at the end.
 //   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).
 //   pub: 224 doubles per team: 2 x 96 published cells ([0,36) column, [36,72) row, [80] pivot, [95] always zero), rsd[32]
-template <int EPT>
+template <int EPT, int TEAM = 128>
 __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
   const int nA = m * (m + 1) / 2, nE = 2 * nA;
   double *rsd = pub + 192;
-  for (int i = ttid; i < 192; i += 128) pub[i] = 0.0;
+  for (int i = ttid; i < 192; i += TEAM) pub[i] = 0.0;
   lds_barrier();   // Am was written by other threads; pub is zero
   unsigned pk[EPT];   // o1 [0,7) | o2 [7,14) | khi [14,20) | opub [20,27)
   int eoff[EPT];      // B elements: offset into Bm, else -1
   double val[EPT];
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
-    const int e = ttid + 128 * r;
+    const int e = ttid + TEAM * r;
     pk[r] = 95u | (95u << 7) | (63u << 14) | (95u << 20); eoff[r] = -1; val[r] = 0.0;
     if (e < nE) {
       const int t = e < nA ? 0 : 1;

@@ -1192,7 +1192,7 @@ struct SampleFastArgs {
   const int *mv;
   double *acc;
   int *errflag;
-  int ldN, Mr4, maxP;
+  int ldN, Mr4, maxP, av_dbl;   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
   int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
   double tausq_inv[QMAX];
 };
@@ -1214,8 +1214,9 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   double *wv = Np + (size_t)Mr4 * ldN;           // maxP + 32 : ancestors' w, then the group's new w
   double *tv = wv + A.maxP + 32, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32;
   double *av = zc + 32;                          // MAXJ x 32
-  double *S = av + MAXJ * 32;                    // 32 x CH_LD
-  int *colblk = (int *)(S + 32 * CH_LD);
+  int *colblk = (int *)(av + A.av_dbl);          // 32 ints
+  double *S = av + A.av_dbl + 16;                // reference levels only: 32 x CH_LD
+  double *Li = S + 32 * CH_LD;                   // 32 x CH_LD: chol(S)^{-1}
 
   int gidx = blockIdx.x;
   {
@@ -1259,8 +1260,11 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
     }
   }
   __syncthreads();
-  for (int t = 0; t < J; ++t)
-    for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[s_arow[t] + i];
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+  }
   STAMP(0);
   // panel rows -> LDS (row j of the group = one panel row of its block); pad rows / columns zero.
   // Each wave takes rows wid, wid+4, ...; all loads of four rows are issued before the first LDS store.
@@ -1315,8 +1319,15 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
       const int i = idx / M, j = idx - i * M;
       double a = 0.0;
       if (j <= i) {
-        for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
-        for (int c = 0; c < s_nch; ++c) a += A.acc[s_coff[c] + B0.acc_len + idx];
+        double ch[4];   // the children's records: four loads in flight, fixed summation order
+        for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
+          if (c0 == 0) for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+        }
+        if (s_nch == 0) for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
         if (i == j) a += tsq[i];
       }
       S[i * CH_LD + j] = a;
@@ -1325,7 +1336,13 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
       const int i = tid;
       double a = 0.0;
       for (int k = i; k < M; ++k) a -= Ri[(size_t)k * ldN + i] * tv[k];
-      for (int c = 0; c < s_nch; ++c) a += A.acc[s_coff[c] + B0.acc_len + M * M + i];
+      double ch[4];
+      for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      }
       bv[i] = a + tsq[i] * yx[i];
     }
   }
@@ -1373,15 +1390,21 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
     }
   }
   if (refgrp) {
-    // w_u = L^{-T} (L^{-1} Smu + z): elimination carries the forward solve; the transposed solve walks the pivots back
-    block_chol_eliminate(S, nullptr, bv, M, av, av + 216, &s_fail);
-    if (tid < M) bv[tid] += zc[tid];
-    const double *rsd = av + 216;
-    for (int k = M - 1; k >= 0; --k) {
-      __syncthreads();
-      const double wk = bv[k] * rsd[k];
-      if (tid < k) bv[tid] -= S[k * CH_LD + tid] * wk;
-      if (tid == 32) wv[P + k] = wk;
+    // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I]: two small matrix-vector products
+    // instead of a forward and a backward substitution (m barrier steps each)
+    if (M <= 22) team_chol_eliminate<2, NT>(S, Li, M, M, av, &s_fail, tid);
+    else if (M <= 27) team_chol_eliminate<3, NT>(S, Li, M, M, av, &s_fail, tid);
+    else team_chol_eliminate<5, NT>(S, Li, M, M, av, &s_fail, tid);
+    if (tid < M) {
+      double a = zc[tid];
+      for (int j = 0; j <= tid; ++j) a += Li[tid * CH_LD + j] * bv[j];
+      ev[tid] = a;
+    }
+    __syncthreads();
+    if (tid < M) {
+      double a = 0.0;
+      for (int i = tid; i < M; ++i) a += Li[i * CH_LD + tid] * ev[i];
+      wv[P + tid] = a;
     }
   }
   __syncthreads();
@@ -1430,8 +1453,19 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
     const int ma = s_am[t], oa = s_ao[t];
     if (i < ma) {
       double a = 0.0;
+      double ch[4];   // the children's vectors: requested before the dot product, added after it in a fixed order
+      const int nch = s_nch;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
       for (int r = 0; r < M; ++r) a -= Np[(size_t)r * ldN + oa + i] * av[t * 32 + r];
-      for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      for (int c0 = 4; c0 < nch; c0 += 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nch) ? A.acc[s_coff[min(c0 + cc, nch - 1)] + s_aoff[t] + ma * ma + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      }
       rec[s_aoff[t] + ma * ma + i] = a;
     }
   }
@@ -1735,7 +1769,7 @@ struct LevelInfo {
   bool fast = false;
   int grp_first = 0, grp_count = 0, Pm4 = 0, ldKV = 2, ldS = 2, SRm = 1, stage_dbl = 0;
   size_t lds_fast = 0;
-  int ldN = 2, Mr4 = 4;
+  int ldN = 2, Mr4 = 4, av_dbl = 224;
   size_t lds_sfast = 0;
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
@@ -2206,7 +2240,10 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         L.Mr4 = std::max(4, (maxM + 3) & ~3);
         L.ldN = (L.maxLd + 16 + 1) | 1;   // odd stride, room for the 16-wide tile overshoot
         L.ldN = std::max(L.ldN, L.maxP + 33);
-        const size_t dbl = (size_t)L.Mr4 * L.ldN + (size_t)L.maxP + 32 + 6 * 32 + (size_t)MAXJ * 32 + 32 * CH_LD + 16;
+        int maxJ = 0;
+        for (int b : list) maxJ = std::max(maxJ, h->blks[b].nanc);
+        L.av_dbl = std::max(32 * maxJ, 224);
+        const size_t dbl = (size_t)L.Mr4 * L.ldN + (size_t)L.maxP + 32 + 6 * 32 + (size_t)L.av_dbl + 16 + (L.isref ? 2 * 32 * CH_LD : 0) + 16;
         L.lds_sfast = dbl * 8 + 64 * 4 + 64;
         ok = L.lds_sfast <= h->lds_limit;
       }
@@ -2818,7 +2855,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.do_gram = A.do_gram;
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
-        F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.maxP = L.maxP;
+        F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
         hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
       } else if (L.big_sample) {
