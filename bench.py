@@ -17,6 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PMC_SUMMARY = "c_quad_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -151,9 +152,9 @@ def main():
     # separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the workload it was taken on
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "b_mfma_pmc_hbm.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", PMC_SUMMARY)))
         if world == 1 and args.side == 1000 and args.q == 1:
-            traffic = pmc["summary"]["k_factor_mfma"]["hbm_bytes_per_launch"]
+            traffic = pmc["summary"]["phase_A"]["hbm_bytes_per_launch"]
     except Exception:      # noqa: BLE001
         traffic = None
     out = {
