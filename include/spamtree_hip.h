@@ -100,6 +100,10 @@ int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter);
 /* ---- phase C: get_loglik_w_std(data) (spamtree_model.cpp:781-826) */
 int st_loglik_w(st_handle h, int slot, double *loglik);
 
+/* st_sample_w followed by st_loglik_w(slot), same results and return codes (the sweep's 10 / 11 first), with a single
+ * host synchronisation: what the MCMC driver calls once per iteration (spamtree_fit.cpp:182-185). */
+int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot, double *loglik);
+
 /* ---- phase P: predict_std(true, theta_changed) on param_data (spamtree_model.cpp:1234-1358); uses the last sweep's z */
 int st_predict(st_handle h, int theta_changed);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "st_swap": (C.c_int, [H]),
     "st_sample_w": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32]),
     "st_loglik_w": (C.c_int, [H, C.c_int, c_dp]),
+    "st_sample_w_loglik": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32, C.c_int, c_dp]),
     "st_predict": (C.c_int, [H, C.c_int]),
     "st_beta_stats": (C.c_int, [H, c_dp]),
     "st_tausq_stats": (C.c_int, [H, c_dp, c_ip]),

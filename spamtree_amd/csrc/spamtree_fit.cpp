@@ -226,10 +226,9 @@ static int step_w_theta(stm_chain c) {
   const uint32_t m = (uint32_t)c->m;
   int rc;
   if (c->sample_w) {
-    rc = st_sample_w(c->h, nullptr, c->seed, m);
+    rc = st_sample_w_loglik(c->h, nullptr, c->seed, m, 0, &c->loglik[0]);   // deal_with_w + get_loglik_w (:182-185)
     if (rc > 0) { c->err = "Error at gibbs_sample_w"; return rc; }
     if (rc < 0) { c->err = st_last_error(c->h); return rc; }
-    if ((rc = st_loglik_w(c->h, 0, &c->loglik[0])) != 0) { c->err = st_last_error(c->h); return rc; }
     c->current_loglik = c->loglik[0];
   }
   if (c->sample_theta) {

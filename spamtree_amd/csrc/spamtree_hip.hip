@@ -1812,6 +1812,9 @@ struct st_handle_s {
   long long n_summary = 0;
   int factor_gen = 1;
   bool stats_valid = false;                   // d_stats matches the current w and XB
+  bool host_stats_valid = false;              // ... and host_stats holds a copy of it
+  std::vector<double> host_stats;
+  double *pin = nullptr;                      // 64 doubles of pinned host memory for the small device-to-host reads
   bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
   bool cache_gram = true;
   ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
@@ -1929,6 +1932,7 @@ extern "C" int st_destroy(st_handle h) {
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
+  if (h->pin) (void)hipHostFree(h->pin);
   if (h->stream && !h->ext_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ST_OK;
@@ -2420,6 +2424,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     if (e_ != hipSuccess) return fail_create(h, ST_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
   CCHK(hipStreamCreate(&h->stream));
+  CCHK(hipHostMalloc((void **)&h->pin, 64 * sizeof(double), hipHostMallocDefault));
   CCHK(h->d_cx.upload(cx)); CCHK(h->d_cy.upload(cy)); CCHK(h->d_y.upload(y)); CCHK(h->d_X.upload(X));
   CCHK(h->d_mv.upload(mv)); CCHK(h->d_obs.upload(obs)); CCHK(h->d_partner.upload(partner));
   CCHK(h->d_dev2model.upload(h->dev2model));
@@ -2538,7 +2543,7 @@ static int download_rows(st_handle h, const double *src, double *dst) {
 
 extern "C" int st_set_w(st_handle h, const double *w) {
   if (!h || !w) return ST_ERR_USAGE;
-  h->stats_valid = false;
+  h->stats_valid = false; h->host_stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   return upload_rows(h, w, h->d_w.p);
 }
@@ -2554,7 +2559,7 @@ extern "C" int st_get_xb(st_handle h, double *xb) {
 }
 extern "C" int st_set_beta(st_handle h, const double *Bcoeff) {
   if (!h || !Bcoeff) return ST_ERR_USAGE;
-  h->stats_valid = false;
+  h->stats_valid = false; h->host_stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   HCHK(h, hipMemcpyAsync(h->d_B.p, Bcoeff, (size_t)h->p * h->q * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
@@ -2812,14 +2817,48 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
   }
   int rc = st_factor_local(h, slot, theta, ntheta);
   if (rc) return rc;
-  int code = 0;
-  rc = read_err(h, &code);
+  // the failure word and the two sums come back in ONE synchronisation (the sums are meaningless after a failure)
+  {
+    ProfScope ps(h, 3);
+    const int phys = h->slot_map[slot];
+    launch_sum2(h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p + 8, h->d_scalars.p);
+  }
+  HCHK(h, hipGetLastError());
+  HCHK(h, hipMemcpyAsync(h->pin, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipMemcpyAsync(h->pin + 2, h->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  const int e0 = ((const int *)(h->pin + 2))[0];
+  if (e0 != INT_MAX) return e0 & 15;  // the reference's `return false` (:971-982); deeper levels hold unspecified values (Q5)
+  if (loglik) *loglik = h->pin[0] + h->pin[1];   // loglik_w = logdetCi + sum(loglik_w_comps)  (:987-988)
+  return ST_OK;
+}
+
+// st_sample_w followed by st_loglik_w(slot) with ONE synchronisation (the sweep's failure word travels with the sums).
+extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot, double *loglik) {
+  if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  if (h->world > 1) {
+    int rc = st_sample_w(h, z, seed, iter);
+    if (rc) return rc;
+    return st_loglik_w(h, slot, loglik);
+  }
+  int rc = st_sample_w_local(h, z, seed, iter);
   if (rc) return rc;
-  if (code) return code;  // the reference's `return false` (:971-982); deeper levels hold unspecified values (Q5)
-  double ll = 0.0;
-  rc = reduce_loglik(h, h->slot_map[slot], &ll);
+  rc = st_sample_w_top(h);
   if (rc) return rc;
-  if (loglik) *loglik = ll;
+  HCHK(h, hipMemcpyAsync(h->pin + 2, h->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  rc = st_loglik_local(h, slot);   // resets the failure word after the copy above (stream order)
+  if (rc) return rc;
+  {
+    ProfScope ps(h, 3);
+    const int phys = h->slot_map[slot];
+    launch_sum2(h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p + 8, h->d_scalars.p);
+  }
+  HCHK(h, hipGetLastError());
+  HCHK(h, hipMemcpyAsync(h->pin, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  const int e0 = ((const int *)(h->pin + 2))[0];
+  if (e0 != INT_MAX) return e0 & 15;  // 10 / 11: the reference stops with "Error at gibbs_sample_w" (:1215-1217)
+  if (loglik) *loglik = h->pin[0] + h->pin[1];
   return ST_OK;
 }
 
@@ -2874,7 +2913,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
 // that an all-reduce(sum) over st_mg_top_region() completes them
 extern "C" int st_sample_w_local(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false;
+  h->stats_valid = false; h->host_stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   int rc = gen_or_upload_z(h, z, seed, iter, 0u, h->d_z.p);
   if (rc) return rc;
@@ -2894,7 +2933,7 @@ extern "C" int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len) {
 }
 extern "C" int st_sample_w_top(st_handle h) {   // the replicated levels above the cut
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false;
+  h->stats_valid = false; h->host_stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   const int rc = sample_launch(h, std::min(h->cut, h->n_actual_groups), 0);
   if (rc == ST_OK) h->gram_valid = true;   // every record now carries the Gram sums of the accepted theta
@@ -2913,7 +2952,7 @@ extern "C" int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len) {
 }
 extern "C" int st_mg_unpack_w(st_handle h) {
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false;
+  h->stats_valid = false; h->host_stats_valid = false;
   HCHK(h, hipSetDevice(h->device));
   double errw[64];
   HCHK(h, hipMemcpyAsync(h->d_w.p, h->d_tmp_n.p, (size_t)h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -2995,7 +3034,7 @@ extern "C" int st_predict(st_handle h, int theta_changed) {
   (void)theta_changed;  // H of a prediction block is rebuilt from the ancestor chain every call: same values as the cache
   if (!h) return ST_ERR_USAGE;
   if (h->pred_list.empty()) return ST_OK;
-  h->stats_valid = false;
+  h->stats_valid = false; h->host_stats_valid = false;
   if (!h->z_valid) { h->err = "st_predict needs the normals of a preceding st_sample_w (spamtree_model.cpp:1325)"; return ST_ERR_USAGE; }
   if (h->theta[0].empty()) { h->err = "st_predict before st_factor(slot 0)"; return ST_ERR_USAGE; }
   HCHK(h, hipSetDevice(h->device));
@@ -3032,22 +3071,32 @@ static int run_stats(st_handle h) {
   h->stats_valid = true;
   return ST_OK;
 }
+// both statistics travel to the host together; a second request for the same (w, XB) is served from the host copy
+static int fetch_stats(st_handle h) {
+  if (h->stats_valid && h->host_stats_valid) return ST_OK;
+  int rc = run_stats(h);
+  if (rc) return rc;
+  const size_t nq = (size_t)h->p * h->q + h->q;
+  h->host_stats.resize(nq);
+  HCHK(h, hipMemcpyAsync(h->host_stats.data(), h->d_stats.p, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  h->host_stats_valid = true;
+  return ST_OK;
+}
 extern "C" int st_beta_stats(st_handle h, double *xty) {
   if (!h || !xty) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
-  int rc = run_stats(h);
+  int rc = fetch_stats(h);
   if (rc) return rc;
-  HCHK(h, hipMemcpyAsync(xty, h->d_stats.p, (size_t)h->p * h->q * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HCHK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->p * h->q; ++i) xty[i] = h->host_stats[i];
   return ST_OK;
 }
 extern "C" int st_tausq_stats(st_handle h, double *ssq, int64_t *n_obs_by_q) {
   if (!h || !ssq) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
-  int rc = run_stats(h);
+  int rc = fetch_stats(h);
   if (rc) return rc;
-  HCHK(h, hipMemcpyAsync(ssq, h->d_stats.p + (size_t)h->p * h->q, (size_t)h->q * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HCHK(h, hipStreamSynchronize(h->stream));
+  for (int j = 0; j < h->q; ++j) ssq[j] = h->host_stats[(size_t)h->p * h->q + j];
   if (n_obs_by_q)
     for (int j = 0; j < h->q; ++j) n_obs_by_q[j] = h->n_obs_q[j];
   return ST_OK;
