@@ -1556,7 +1556,7 @@ struct LoglikGrpArgs {
   int maxP;
 };
 
-__global__ __launch_bounds__(NT) void k_loglik_grp(LoglikGrpArgs A) {
+__global__ __launch_bounds__(NT, 8) void k_loglik_grp(LoglikGrpArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ];
@@ -1592,38 +1592,44 @@ __global__ __launch_bounds__(NT) void k_loglik_grp(LoglikGrpArgs A) {
     s_cb[j] = bi;
   }
   __syncthreads();
-  for (int k = tid; k < P; k += NT) {
-    int t = 0;
-    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
-    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
-  }
-  // this wave's rows wid, wid + 4, ...: every load is issued before the first LDS read of w
+  // this wave's rows wid, wid + 4, ... in two batches of four rows; all of a batch's loads are issued before anything
+  // waits.  <= 64 VGPRs: eight workgroups per CU keep the memory system busy.
   const int rowlen = P + (refgrp ? M : 1);
-  double v[8][5];
+#pragma unroll 1
+  for (int b = 0; b < 2; ++b) {
+    double v[4][5];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int j = wid + 4 * rr, jc = min(j, M - 1);
-    const int bi = s_cb[jc];
-    const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr), jc = min(j, M - 1);
+      const int bi = s_cb[jc];
+      const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
 #pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int k = lane + 64 * c;
-      v[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
+      for (int c = 0; c < 5; ++c) {
+        const int k = lane + 64 * c;
+        v[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
+      }
     }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int j = wid + 4 * rr;
-    double acc = 0.0;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int k = lane + 64 * c;
-      const double wk = k < P ? wv[k] : (refgrp ? (k < rowlen ? wv[k] : 0.0) : wv[P + min(j, 31)]);
-      acc += v[rr][c] * wk;
+    if (b == 0) {
+      for (int k = tid; k < P; k += NT) {
+        int t = 0;
+        while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+        wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+      }
+      __syncthreads();
     }
-    acc = wave_sum(acc);
-    if (lane == 0 && j < 32) s_e2[j] = acc * acc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int k = lane + 64 * c;
+        const double wk = k < P ? wv[k] : (refgrp ? (k < rowlen ? wv[k] : 0.0) : wv[P + min(j, 31)]);
+        acc += v[rr][c] * wk;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0 && j < 32) s_e2[j] = acc * acc;
+    }
   }
   __syncthreads();
   if (tid < G.nblk) {
