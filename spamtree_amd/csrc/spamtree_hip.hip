@@ -1192,7 +1192,7 @@ struct SampleFastArgs {
   const int *mv;
   double *acc;
   int *errflag;
-  int ldN, Mr4, maxP, av_dbl;   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
+  int ldN, Mr4, Mrows, maxP, av_dbl;   // Mrows: staged panel rows (the level's largest group)   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
   int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
   double tausq_inv[QMAX];
 };
@@ -1210,13 +1210,13 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int ldN = A.ldN, Mr4 = A.Mr4;
-  double *Np = lds;                              // Mr4 x ldN
-  double *wv = Np + (size_t)Mr4 * ldN;           // maxP + 32 : ancestors' w, then the group's new w
+  double *Np = lds;                              // maxM x ldN (no pad rows: the Gram tiles mask rows >= M)
+  double *wv = Np + (size_t)A.Mrows * ldN + 32;  // maxP + 32 : ancestors' w, then the group's new w
   double *tv = wv + A.maxP + 32, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32;
   double *av = zc + 32;                          // MAXJ x 32
   int *colblk = (int *)(av + A.av_dbl);          // 32 ints
-  double *S = av + A.av_dbl + 16;                // reference levels only: 32 x CH_LD
-  double *Li = S + 32 * CH_LD;                   // 32 x CH_LD: chol(S)^{-1}
+  double *S = av + A.av_dbl + 16;                // reference levels only: maxM x CH_LD
+  double *Li = S;                                // chol(S)^{-1} replaces S (the elimination reads S once, writes at the end)
 
   int gidx = blockIdx.x;
   {
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int j = jb + wid + 4 * rr;
-      if (j < Mr4) {
+      if (j < M) {
         double *dst = Np + (size_t)j * ldN;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1360,7 +1360,9 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
       const double *ap = Np + (size_t)l4 * ldN + oa + it * 16 + l15;
       const double *bp = Np + (size_t)l4 * ldN + oa + jt * 16 + l15;
       for (int st = 0; st < nsteps; ++st) {
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], c, 0, 0, 0);
+        const bool rok = 4 * st + l4 < M;   // rows >= M are not staged; columns past the ancestor's m only feed discarded entries
+        const double av_ = rok ? ap[0] : 0.0, bv_ = rok ? bp[0] : 0.0;
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av_, bv_, c, 0, 0, 0);
         ap += 4 * ldN; bp += 4 * ldN;
       }
       double *out = rec + s_aoff[t];
@@ -1775,7 +1777,7 @@ struct LevelInfo {
   bool fast = false;
   int grp_first = 0, grp_count = 0, Pm4 = 0, ldKV = 2, ldS = 2, SRm = 1, stage_dbl = 0;
   size_t lds_fast = 0;
-  int ldN = 2, Mr4 = 4, av_dbl = 224;
+  int ldN = 2, Mr4 = 4, Mrows = 1, av_dbl = 224;
   size_t lds_sfast = 0;
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
@@ -2248,12 +2250,12 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       }
       if (ok) {
         L.Mr4 = std::max(4, (maxM + 3) & ~3);
-        L.ldN = (L.maxLd + 16 + 1) | 1;   // odd stride, room for the 16-wide tile overshoot
-        L.ldN = std::max(L.ldN, L.maxP + 33);
+        L.Mrows = std::max(1, maxM);
+        L.ldN = L.maxLd | 1;              // odd stride >= the longest panel row
         int maxJ = 0;
         for (int b : list) maxJ = std::max(maxJ, h->blks[b].nanc);
         L.av_dbl = std::max(32 * maxJ, 224);
-        const size_t dbl = (size_t)L.Mr4 * L.ldN + (size_t)L.maxP + 32 + 6 * 32 + (size_t)L.av_dbl + 16 + (L.isref ? 2 * 32 * CH_LD : 0) + 16;
+        const size_t dbl = (size_t)maxM * L.ldN + 32 + (size_t)L.maxP + 32 + 6 * 32 + (size_t)L.av_dbl + 16 + (L.isref ? (size_t)maxM * CH_LD : 0) + 16;
         L.lds_sfast = dbl * 8 + 64 * 4 + 64;
         ok = L.lds_sfast <= h->lds_limit;
       }
@@ -2900,7 +2902,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.do_gram = A.do_gram;
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
-        F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
+        F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.Mrows = L.Mrows; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
         hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
       } else if (L.big_sample) {
