@@ -46,19 +46,23 @@ struct QuadArgs {
 // scaled by 1 / sqrt(d_i) once at the end.
 //   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).
 //   pub: 224 doubles per team: 2 x 96 published cells ([0,36) column, [36,72) row, [80] pivot, [95] always zero), rsd[32]
+typedef __attribute__((address_space(3))) double q_lds_double;
 template <int EPT, int TEAM = 128>
 __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
   const int nA = m * (m + 1) / 2, nE = 2 * nA;
   double *rsd = pub + 192;
   for (int i = ttid; i < 192; i += TEAM) pub[i] = 0.0;
   lds_barrier();   // Am was written by other threads; pub is zero
-  unsigned pk[EPT];   // o1 [0,7) | o2 [7,14) | khi [14,20) | opub [20,27)
-  int eoff[EPT];      // B elements: offset into Bm, else -1
+  // per element: 32-bit LDS addresses of its two factors and of its publication cell in buffer 0 (buffer 1 = +96
+  // doubles, an immediate offset in the unrolled pivot pair below), the pivot at which it is published, its output slot
+  q_lds_double *p1[EPT], *p2[EPT], *pp[EPT];
+  int khi[EPT], eoff[EPT];
   double val[EPT];
+  q_lds_double *pub3 = (q_lds_double *)pub;
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int e = ttid + TEAM * r;
-    pk[r] = 95u | (95u << 7) | (63u << 14) | (95u << 20); eoff[r] = -1; val[r] = 0.0;
+    p1[r] = pub3 + 95; p2[r] = pub3 + 95; pp[r] = pub3 + 94; khi[r] = -1; eoff[r] = -1; val[r] = 0.0;
     if (e < nE) {
       const int t = e < nA ? 0 : 1;
       const int f = e - t * nA;
@@ -66,37 +70,40 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
       while (i * (i + 1) / 2 > f) --i;
       while ((i + 1) * (i + 2) / 2 <= f) ++i;
       const int j = f - i * (i + 1) / 2;
-      const unsigned o1 = i, o2 = t == 0 ? j : 36 + j, khi = t == 0 ? j : i;
-      const unsigned opub = t == 0 ? (i == j ? 80 : i) : 36 + j;
-      pk[r] = o1 | (o2 << 7) | (khi << 14) | (opub << 20);
+      p1[r] = pub3 + i;
+      p2[r] = pub3 + (t == 0 ? j : 36 + j);
+      pp[r] = pub3 + (t == 0 ? (i == j ? 80 : i) : 36 + j);
+      khi[r] = t == 0 ? j : i;
       eoff[r] = t == 1 ? i * CH_LD + j : -1;
       val[r] = t == 0 ? Am[i * CH_LD + j] : (i == j ? 1.0 : 0.0);
     }
   }
-  for (int k = 0; k < mmax; ++k) {
-    double *pa = pub + (k & 1) * 96;
-#pragma unroll
-    for (int r = 0; r < EPT; ++r)
-      if ((unsigned)k == ((pk[r] >> 14) & 63u)) pa[(pk[r] >> 20) & 127u] = val[r];
-    if (ttid == 0) { pa[k] = 0.0; if (k > 0) pa[k - 1] = 0.0; }   // rows <= k of the column cells hold older pivots' data
-    lds_barrier();
-    if (k < m) {
-      const double d = pa[80];
-      if (ttid == 0) { if (!(d > 0.0)) *fail = 1; rsd[k] = rsqrt(d); }
-      double rd = __builtin_amdgcn_rcp(d);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-#pragma unroll
-      for (int r = 0; r < EPT; ++r) {
-        const double x1 = pa[pk[r] & 127u], x2 = pa[(pk[r] >> 7) & 127u];
-        val[r] = fma(-(x1 * x2), rd, val[r]);
-      }
-    }
+#define TCH_PIVOT(k_, PAR)                                                                                     \
+  {                                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < EPT; ++r) if ((k_) == khi[r]) pp[r][(PAR) * 96] = val[r];            \
+    if (ttid == 0) { pub3[(PAR) * 96 + (k_)] = 0.0; if ((k_) > 0) pub3[(PAR) * 96 + (k_) - 1] = 0.0; }          \
+    lds_barrier();                                                                                             \
+    if ((k_) < m) {                                                                                            \
+      const double d = pub3[(PAR) * 96 + 80];                                                                  \
+      if (ttid == 0) { if (!(d > 0.0)) *fail = 1; rsd[(k_)] = rsqrt(d); }                                      \
+      double rd = __builtin_amdgcn_rcp(d);                                                                     \
+      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
+      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
+      _Pragma("unroll") for (int r = 0; r < EPT; ++r) {                                                        \
+        const double x1 = p1[r][(PAR) * 96], x2 = p2[r][(PAR) * 96];                                           \
+        val[r] = fma(-(x1 * x2), rd, val[r]);                                                                  \
+      }                                                                                                        \
+    }                                                                                                          \
   }
+  for (int k = 0; k < mmax; k += 2) {
+    TCH_PIVOT(k, 0)
+    if (k + 1 < mmax) TCH_PIVOT(k + 1, 1)
+  }
+#undef TCH_PIVOT
   lds_barrier();   // rsd complete
 #pragma unroll
   for (int r = 0; r < EPT; ++r)
-    if (eoff[r] >= 0) Bm[eoff[r]] = val[r] * rsd[(pk[r] >> 14) & 63u];
+    if (eoff[r] >= 0) Bm[eoff[r]] = val[r] * rsd[khi[r]];
   lds_barrier();
 }
 
