@@ -81,10 +81,11 @@ __device__ __forceinline__ double cov_exp(double x) {
   return __builtin_ldexp(p, (int)t);   // |t| < 2^31 after the clamp above, or +huge -> saturating conversion -> inf
 }
 
-// sqrt(a) for squared distances: v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections (the library's
-// scheme without its range scaling; correctly rounded in the range taken here); anything else goes to the library.
+// sqrt(a) for squared distances (a >= 0): v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections (the
+// library's scheme without its range scaling).  a is clamped to 1e-300 from below, so coincident points give 1e-150
+// instead of 0 (exp(-phi * 1e-150) == 1 exactly); squared distances above ~1e300 are outside the contract.
 __device__ __forceinline__ double cov_sqrt(double a) {
-  if (!(a > 1e-280 && a < 1e280)) return sqrt(a);   // 0 (coincident points), denormal-small, huge, NaN
+  a = fmax(a, 1e-300);
   const double y = __builtin_amdgcn_rsq(a);
   double g = a * y, h = 0.5 * y;
   const double r = fma(-h, g, 0.5);
