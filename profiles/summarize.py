@@ -31,18 +31,18 @@ if os.path.exists(b):
     line = [x for x in open(b).read().strip().splitlines() if x.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
 
-st = glob.glob(os.path.join(src, f"{tag}_trace", "*", "*kernel_stats.csv"))
+st = sorted(glob.glob(os.path.join(src, f"{tag}_trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)   # newest run
 if st:
-    shutil.copy(st[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    shutil.copy(st[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
 out = {"units": "bytes", "note": "FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported; per launch = mean over launches"}
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    fs = glob.glob(os.path.join(src, f"{tag}_pmc_{c}", "*", "*counter_collection.csv"))
+    fs = sorted(glob.glob(os.path.join(src, f"{tag}_pmc_{c}", "*", "*counter_collection.csv")), key=os.path.getmtime)
     if not fs:
         continue
     by = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(fs[-1])):
         if r.get("Counter_Name") == c:
             by[family(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0)
     per[c] = {k: {"launches": len(v), "mean_bytes": sum(v) / len(v), "total_bytes": sum(v)} for k, v in by.items()}
