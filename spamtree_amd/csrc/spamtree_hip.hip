@@ -1478,6 +1478,218 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Phase B, fast path, sweeps that keep the cached Gram parts (do_gram == 0: every sweep between two accepted theta).
+// Same results as k_sample_mfma up to rounding, but the panel is never staged in LDS: it is read twice from global
+// memory (L2 / Infinity Cache the second time) with a thread mapping chosen per pass --
+//   pass 1: thread (row r, ancestor t) sums its 25-or-so products N[r][oa_t + j] w_a[j]: the segment sums give both
+//           tv = N w_pa (their sum over t) and, later, av_t = ev - N_t w_t, with no cross-lane reduction;
+//   pass 2: thread k (a chain column) accumulates -sum_r N[r][k] av_t(k)[r]: coalesced rows, no reduction either.
+// LDS holds vectors only (plus the m x m posterior precision of reference blocks): ~6-19 KB instead of 50-55 KB, so
+// 6-8 workgroups share a CU and their latency chains overlap.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 6) void k_sample_lean(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
+  __shared__ int s_bld[32], s_cb[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];
+  __shared__ int s_nch;
+
+  const int tid = threadIdx.x;
+  double *wv = lds;                                  // maxP + 32 : ancestors' w, then the group's new w
+  double *seg = wv + A.maxP + 32;                    // av_dbl : seg[t][r], later av[t][r]; elimination scratch in between
+  double *tv = seg + A.av_dbl + 16, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32, *rjv = zc + 32;
+  double *Rc = rjv + 32;                             // reference levels only: Ri, 32 x CH_LD
+  double *S = Rc + 32 * CH_LD;                       // 32 x CH_LD: posterior precision, then its inverse Cholesky factor
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  const Grp G = A.grps[gidx];
+  const int M = G.M, P = G.P;
+  const Blk B0 = A.blks[G.blk0];
+  const int J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid < J) {
+    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + tid]];
+    s_am[tid] = Ba.m; s_arow[tid] = Ba.row0;
+  }
+  if (tid >= 64 && tid < 64 + G.nblk) {
+    const Blk Bb = A.blks[G.blk0 + tid - 64];
+    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
+  }
+  if (tid >= 128 && tid < 128 + min(B0.ndch, 64)) s_coff[tid - 128] = A.blks[A.dch_idx[B0.dch_ptr + tid - 128]].acc_off;
+  if (tid == 0) { s_fail = 0; s_nch = min(B0.ndch, 64); }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    long long ao = 0;
+    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+    s_ao[J] = o; s_aoff[J] = ao;
+  }
+  if (tid >= 32 && tid < 64) {
+    const int j = tid - 32;
+    double t_ = 0.0, y_ = 0.0, z_ = 0.0, r_ = 0.0;
+    int bi = 0;
+    long long ro = 0;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
+      while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
+      ro = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+      if (!refgrp) r_ = A.panels[ro + P];
+    }
+    tsq[j] = t_; yx[j] = y_; zc[j] = z_; rjv[j] = r_; s_cb[j] = bi; s_rowoff[j] = ro;
+  }
+  __syncthreads();
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+  }
+  if (refgrp) {   // Ri -> LDS (rows of the panel's last M columns)
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      Rc[i * CH_LD + j] = (j <= i) ? A.panels[s_rowoff[i] + P + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
+  for (int idx = tid; idx < M * J; idx += NT) {
+    const int r = idx / J, t = idx - r * J;
+    const int ma = s_am[t], oa = s_ao[t];
+    const double *row = A.panels + s_rowoff[r] + oa;
+    const double *wa = wv + oa;
+    double a = 0.0;
+    for (int j0 = 0; j0 < ma; j0 += 8) {
+      double x[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+    }
+    seg[t * 32 + r] = a;
+  }
+  __syncthreads();
+  if (tid < M) {
+    double a = 0.0;
+    for (int t = 0; t < J; ++t) a += seg[t * 32 + tid];
+    tv[tid] = a;
+  }
+  __syncthreads();
+  if (refgrp) {
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      double a = 0.0;
+      if (j <= i) {
+        double ch[4];   // the children's records: four loads in flight, fixed summation order
+        for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
+          if (c0 == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+        }
+        if (s_nch == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
+        if (i == j) a += tsq[i];
+      }
+      S[i * CH_LD + j] = a;
+    }
+    if (tid < M) {
+      const int i = tid;
+      double a = 0.0;
+      for (int k = i; k < M; ++k) a -= Rc[k * CH_LD + i] * tv[k];
+      double ch[4];
+      for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      }
+      bv[i] = a + tsq[i] * yx[i];
+    }
+    // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I] (scratch: the pivot cells live after
+    // the segment sums, which stay intact)
+    double *pub = seg + 32 * J;
+    if (M <= 22) team_chol_eliminate<2, NT>(S, S, M, M, pub, &s_fail, tid);
+    else if (M <= 27) team_chol_eliminate<3, NT>(S, S, M, M, pub, &s_fail, tid);
+    else team_chol_eliminate<5, NT>(S, S, M, M, pub, &s_fail, tid);
+    if (tid < M) {
+      double a = zc[tid];
+      for (int j = 0; j <= tid; ++j) a += S[tid * CH_LD + j] * bv[j];
+      ev[tid] = a;
+    }
+    __syncthreads();
+    if (tid < M) {
+      double a = 0.0;
+      for (int i = tid; i < M; ++i) a += S[i * CH_LD + tid] * ev[i];
+      wv[P + tid] = a;
+    }
+    __syncthreads();
+    if (tid < M) {
+      const int i = tid;
+      A.w[G.row0 + i] = wv[P + i];
+      double a = tv[i];
+      for (int j = 0; j <= i; ++j) a += Rc[i * CH_LD + j] * wv[P + j];
+      ev[i] = a;
+    }
+  } else {
+    if (tid < M) {
+      const int j = tid;
+      const double rj = rjv[j];
+      const double sig = rj * rj + tsq[j];
+      if (!(sig > 0.0)) s_fail = 1;
+      const double mu = -rj * tv[j] + tsq[j] * yx[j];
+      const double c = 1.0 / sqrt(sig);
+      const double wj = c * c * mu + c * zc[j];
+      A.w[G.row0 + j] = wj;
+      ev[j] = rj * wj + tv[j];
+    }
+  }
+  __syncthreads();
+  // av[t][r] = ev[r] - seg[t][r]
+  for (int idx = tid; idx < J * 32; idx += NT) {
+    const int r = idx & 31;
+    seg[idx] = (r < M) ? ev[r] - seg[idx] : 0.0;
+  }
+  __syncthreads();
+  // ---- pass 2: vector part of the records, -N_a' av_a + the children's
+  double *rec = A.acc + B0.acc_off;
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    const int ma = s_am[t], i = k - s_ao[t];
+    const double *avt = seg + t * 32;
+    double ch[4];   // the children's vectors: requested first, added after the dot product in a fixed order
+    const int nch = s_nch;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
+    double a = 0.0;
+    for (int r0 = 0; r0 < M; r0 += 8) {
+      double x[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < M) ? A.panels[s_rowoff[min(r0 + rr, M - 1)] + k] : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) a -= x[rr] * avt[min(r0 + rr, 31)];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+    for (int c0 = 4; c0 < nch; c0 += 4) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nch) ? A.acc[s_coff[min(c0 + cc, nch - 1)] + s_aoff[t] + ma * ma + i] : 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+    }
+    rec[s_aoff[t] + ma * ma + i] = a;
+  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Phase C: residual + quadratic form per block (spamtree_model.cpp:781-826)
 // ---------------------------------------------------------------------------------------------------------------
 struct LoglikArgs {
@@ -1779,7 +1991,7 @@ struct LevelInfo {
   int grp_first = 0, grp_count = 0, Pm4 = 0, ldKV = 2, ldS = 2, SRm = 1, stage_dbl = 0;
   size_t lds_fast = 0;
   int ldN = 2, Mr4 = 4, Mrows = 1, av_dbl = 224;
-  size_t lds_sfast = 0;
+  size_t lds_sfast = 0, lds_slean = 0;
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
   int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
@@ -1820,6 +2032,7 @@ struct st_handle_s {
   DevBuf<double> d_sum_w, d_sum_yhat;         // running sums over saved iterations (st_summary_*)
   long long n_summary = 0;
   int factor_gen = 1;
+  int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   bool stats_valid = false;                   // d_stats matches the current w and XB
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
   std::vector<double> host_stats;
@@ -2258,6 +2471,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         L.av_dbl = std::max(32 * maxJ, 224);
         const size_t dbl = (size_t)maxM * L.ldN + 32 + (size_t)L.maxP + 32 + 6 * 32 + (size_t)L.av_dbl + 16 + (L.isref ? (size_t)maxM * CH_LD : 0) + 16;
         L.lds_sfast = dbl * 8 + 64 * 4 + 64;
+        L.lds_slean = ((size_t)L.maxP + 32 + (size_t)L.av_dbl + 224 + 16 + 7 * 32 + (L.isref ? 2 * 32 * CH_LD : 0) + 16) * 8;
         ok = L.lds_sfast <= h->lds_limit;
       }
       L.fast = ok;
@@ -2505,6 +2719,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     // chains <= 200 rows, LDS fits) and k_factor_mfma elsewhere; 1 = k_factor_mfma everywhere
     const char *e = getenv("SPAMTREE_FACTOR_KERNEL");
     h->factor_gen = (e && e[0] == '1') ? 1 : 3;
+    { const char *e2 = getenv("SPAMTREE_SAMPLE_LEAN"); h->sample_lean = (e2 && e2[0] == '0') ? 0 : 1; }
   }
   {
     // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
@@ -2905,7 +3120,9 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.Mrows = L.Mrows; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
-        hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
+        // leaf groups keep the staged kernel (nothing latency-bound to hide there: staging wins)
+        if (F.do_gram || h->sample_lean == 0 || !L.isref) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
+        else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
       } else if (L.big_sample) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
         hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);

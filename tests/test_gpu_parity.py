@@ -151,7 +151,9 @@ def test_generated_sweep_normals_are_the_documented_stream():
 
 
 def test_gram_cache_gives_identical_sweeps():
-    """caching the theta-only part of the messages per accepted theta must not change a single bit."""
+    """caching the theta-only part of the messages per accepted theta must not change the draws.  The first
+    sweep after a factorisation rebuilds the Gram parts in both models (same kernel: bit-identical); later sweeps of the
+    caching model take k_sample_lean on reference levels, the other keeps k_sample_mfma: equal up to rounding."""
     pb = make_problem(side=40, q=1, seed=21, random_coords=True)
     rng = np.random.default_rng(1)
     a = hip_model(pb, tausq=0.2)
@@ -160,7 +162,9 @@ def test_gram_cache_gives_identical_sweeps():
     for it in range(3):
         z = rng.standard_normal(pb["n"])
         a.deal_with_w(z); b.deal_with_w(z)
-        assert np.array_equal(a.get_w(), b.get_w())
+        if it == 0:
+            assert np.array_equal(a.get_w(), b.get_w())
+        assert relerr(a.get_w(), b.get_w()) <= 1e-12
     th2 = pb["theta"] * 1.02
     for m in (a, b):
         m.theta_update(1, th2)
@@ -169,8 +173,32 @@ def test_gram_cache_gives_identical_sweeps():
     for it in range(2):
         z = rng.standard_normal(pb["n"])
         a.deal_with_w(z); b.deal_with_w(z)
-        assert np.array_equal(a.get_w(), b.get_w())
+        assert relerr(a.get_w(), b.get_w()) <= 1e-12
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[6], CASES[8]])
+def test_lean_sample_kernel_matches_staged_kernel(case, monkeypatch):
+    """k_sample_lean (sweeps with cached Gram parts, reference levels) against k_sample_mfma (SPAMTREE_SAMPLE_LEAN=0) and
+    the oracle: w after three sweeps."""
+    pb = make_problem(seed=51, **case)
+    rng = np.random.default_rng(3)
+    zs = [rng.standard_normal(pb["n"]) for _ in range(3)]
+    ws = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("SPAMTREE_SAMPLE_LEAN", lean)
+        hm = hip_model(pb, tausq=0.2)
+        assert hm.get_loglik_comps_w(0)
+        for z in zs:
+            hm.deal_with_w(z)
+        ws.append(hm.get_w().copy())
+        hm.close()
+    om = oracle_model(pb, tausq=0.2)
+    assert om.get_loglik_comps_w(om.param_data)
+    for z in zs:
+        om.gibbs_sample_w(z)
+    assert relerr(ws[0], ws[1]) <= 1e-11
+    assert relerr(ws[0][om.na_ix_all], om.w[om.na_ix_all]) <= REL
 
 
 def test_cross_covariance_ag10_export():

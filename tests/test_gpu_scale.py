@@ -77,6 +77,7 @@ def test_full_size_properties():
     hm.theta_update(1, wl["theta"])
     assert hm.get_loglik_comps_w(1) and hm.loglik_w[1] == ll_a
     # (3) a sweep is bit-reproducible (no atomics in the message reduction) and the device stream is counter-based
+    hm.deal_with_w(None, seed=11, it=3)   # the first sweep after a factorisation also rebuilds the Gram parts (other kernel)
     w_before = hm.get_w().copy()
     hm.deal_with_w(None, seed=11, it=4)
     w1 = hm.get_w().copy()
