@@ -129,8 +129,9 @@ int st_get_comps(st_handle h, int slot, double *logdetCi_comps, double *loglik_w
 /* ---- measurement: algorithmic bytes of one iteration (SURVEY.md section 8d operand-streaming model)
  * out[0..4] = phase A, B, C, messages, S1+S2;  flops[0..2] = A, B, C (may be NULL). */
 int st_algorithmic_bytes(st_handle h, double *out5, double *flops3);
-/* per-kernel-family device time from HIP events recorded on the launch stream around every launch (enable=1);
- * events are harvested lazily, so profiling adds no host synchronisation to the measured region.
+/* per-kernel-family device time from HIP events recorded on the launch stream around every launch (enable=1), or around
+ * the phase-A launches only (enable=2: the roofline measurement at a third of the event traffic; ~60 event records per
+ * iteration cost 4-6 % of the iteration at n = 1e6).  Events are harvested lazily: no host synchronisation is added.
  * families: 0 factor(A) 1 sample(B) 2 loglik(C) 3 reduce 4 stats/xb 5 rng 6 predict */
 #define ST_N_KERNEL_FAMILIES 7
 int st_profile_enable(st_handle h, int enable);

@@ -2060,12 +2060,12 @@ struct st_handle_s {
   bool z_valid = false;
 
   // profiling
-  bool prof = false;
+  int prof = 0;   // 0 off, 1 every kernel family, 2 phase A only (the roofline measurement at the lowest cost)
   double prof_ms[ST_N_KERNEL_FAMILIES] = {0};
   long long prof_n[ST_N_KERNEL_FAMILIES] = {0};
   std::vector<double> prof_level_ms;   // phase-A time per level, accumulated
   std::vector<long long> prof_level_n;
-  struct ProfRec { hipEvent_t a, b; int fam, level; };
+  struct ProfRec { hipEvent_t a, b; int fam, level, count; };   // count: kernel launches inside the bracket
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> ev_free;
 };
@@ -2099,7 +2099,7 @@ static void prof_harvest(st_handle_s *h) {
     float ms = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       h->prof_ms[r.fam] += ms;
-      h->prof_n[r.fam] += 1;
+      h->prof_n[r.fam] += r.count;
       if (r.level >= 0 && r.level < (int)h->prof_level_ms.size()) { h->prof_level_ms[r.level] += ms; h->prof_level_n[r.level] += 1; }
     }
     h->ev_free.push_back(r.a);
@@ -2110,12 +2110,14 @@ static void prof_harvest(st_handle_s *h) {
 struct ProfScope {
   st_handle_s *h;
   st_handle_s::ProfRec r;
-  ProfScope(st_handle_s *h_, int fam, int level = -1) : h(h_) {
-    r.fam = fam; r.level = level; r.a = r.b = nullptr;
-    if (h->prof) { r.a = prof_event(h); r.b = prof_event(h); (void)hipEventRecord(r.a, h->stream); }
+  // mode 1: every launch is bracketed; mode 2: only the whole-phase bracket of phase A (level == -2), one pair of events
+  ProfScope(st_handle_s *h_, int fam, int level = -1, int count = 1) : h(h_) {
+    r.fam = fam; r.level = level; r.count = count; r.a = r.b = nullptr;
+    const bool on = level == -2 ? h->prof == 2 : h->prof == 1;
+    if (on) { r.a = prof_event(h); r.b = prof_event(h); (void)hipEventRecord(r.a, h->stream); }
   }
   ~ProfScope() {
-    if (h->prof && r.a && r.b) {
+    if (r.a && r.b) {
       (void)hipEventRecord(r.b, h->stream);
       h->prof_pending.push_back(r);
       if (h->prof_pending.size() > 8192) prof_harvest(h);
@@ -2909,6 +2911,9 @@ __global__ void k_pack_w(const double *w, const unsigned char *mask, long long n
 }
 
 static int factor_launch(st_handle h, int phys, const CovPar &cp) {
+  int n_launch = 0;
+  for (int g = 0; g < h->n_actual_groups; ++g) n_launch += ((h->levels[g].fast ? h->levels[g].gown_n : h->levels[g].own_n) != 0);
+  ProfScope phase(h, 0, -2, n_launch);   // profile mode 2: the phase's launches between ONE pair of events (mean launch = total / launches)
   for (int g = 0; g < h->n_actual_groups; ++g) {
     const LevelInfo &L = h->levels[g];
     if ((L.fast ? L.gown_n : L.own_n) == 0) continue;
@@ -3404,7 +3409,7 @@ extern "C" int st_algorithmic_bytes(st_handle h, double *out5, double *flops3) {
 }
 extern "C" int st_profile_enable(st_handle h, int enable) {
   if (!h) return ST_ERR_USAGE;
-  h->prof = enable != 0;
+  h->prof = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
   return ST_OK;
 }
 extern "C" int st_profile_get(st_handle h, double *ms_total, int64_t *launches) {

@@ -105,7 +105,7 @@ class Chain:
                     flops_B=fl[1], flops_C=fl[2])
 
     def profile(self, enable):
-        self.lib.st_profile_enable(self.h, int(bool(enable)))
+        self.lib.st_profile_enable(self.h, 2 if enable == 2 else int(bool(enable)))
 
     def profile_get(self):
         ms, n = np.zeros(7), np.zeros(7, dtype=np.int64)

@@ -253,7 +253,7 @@ class SpamTreeMV:
                     flops_A=fl[0], flops_B=fl[1], flops_C=fl[2])
 
     def profile(self, enable):
-        self._check(self.lib.st_profile_enable(self.h, int(bool(enable))))
+        self._check(self.lib.st_profile_enable(self.h, 2 if enable == 2 else int(bool(enable))))
 
     def profile_get(self):
         ms = np.zeros(7)
