@@ -1690,6 +1690,158 @@ __global__ __launch_bounds__(NT, 6) void k_sample_lean(SampleFastArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Phase B, fast path, leaf (non-reference) groups on sweeps that keep the cached Gram parts.  The rows of a leaf group
+// are independent given the ancestors (diagonal Ri), so a wave owns whole rows: lanes hold the row's columns (coalesced
+// loads, registers only), the per-ancestor segment sums come from masked butterfly reductions, the draw, the residual
+// and the row's contribution -N[r][k] av_t(k)[r] to every chain column follow without leaving the wave; only the
+// column sums over the four waves go through LDS.  One pass over the panel, ~10 KB of LDS, one barrier pair.
+// ---------------------------------------------------------------------------------------------------------------
+// sum over the 64 lanes, returned wave-uniform, without touching the LDS crossbar: rotate-and-add inside each row of 16
+// lanes (DPP row_ror 8, 4, 2, 1), then the four row sums (lanes 0, 16, 32, 48) through v_readlane, added in that order
+__device__ __forceinline__ double dpp_ror_add(double x, const int ctrl_sel) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int lo2, hi2;
+  if (ctrl_sel == 8) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false); }
+  else if (ctrl_sel == 4) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false); }
+  else if (ctrl_sel == 2) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xf, 0xf, false); }
+  else { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, false); }
+  return x + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_allsum(double x) {
+  x = dpp_ror_add(x, 8); x = dpp_ror_add(x, 4); x = dpp_ror_add(x, 2); x = dpp_ror_add(x, 1);
+  const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
+  return ((r0 + r1) + r2) + r3;
+}
+
+__global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
+  __shared__ int s_bld[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];
+  __shared__ int s_nch;
+  __shared__ double s_seg[NT / 64][MAXJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *wv = lds;                       // maxP + 32
+  double *red = wv + A.maxP + 32;         // 4 x 256: per-wave column sums
+  double *tsq = red + 4 * 256, *yx = tsq + 32, *zc = yx + 32;
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  const Grp G = A.grps[gidx];
+  const int M = G.M, P = G.P;
+  const Blk B0 = A.blks[G.blk0];
+  const int J = B0.nanc;
+  if (tid < J) {
+    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + tid]];
+    s_am[tid] = Ba.m; s_arow[tid] = Ba.row0;
+  }
+  if (tid >= 64 && tid < 64 + G.nblk) {
+    const Blk Bb = A.blks[G.blk0 + tid - 64];
+    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
+  }
+  if (tid >= 128 && tid < 128 + min(B0.ndch, 64)) s_coff[tid - 128] = A.blks[A.dch_idx[B0.dch_ptr + tid - 128]].acc_off;
+  if (tid == 0) { s_fail = 0; s_nch = min(B0.ndch, 64); }
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0;
+    long long ao = 0;
+    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+    s_ao[J] = o; s_aoff[J] = ao;
+  }
+  if (tid >= 32 && tid < 64) {
+    const int j = tid - 32;
+    double t_ = 0.0, y_ = 0.0, z_ = 0.0;
+    long long ro = 0;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
+      int bi = 0;
+      while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
+      ro = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+    }
+    tsq[j] = t_; yx[j] = y_; zc[j] = z_; s_rowoff[j] = ro;
+  }
+  __syncthreads();
+  // this lane's columns k = lane + 64 c (P + 1 <= 256 columns: the host routes longer chains to k_sample_mfma)
+  int tk[4];
+  double wk[4], acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = lane + 64 * c;
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    tk[c] = k < P ? t : -1;
+    wk[c] = k < P ? A.w[s_arow[t] + (k - s_ao[t])] : 0.0;
+    acc[c] = 0.0;
+  }
+  const int lastc = P >> 6, lastl = P & 63;   // where column P (the row's r_j) lives
+#pragma unroll 1
+  for (int b = 0; b < 2; ++b) {
+    double v[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      const double *src = A.panels + s_rowoff[min(j, M - 1)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = lane + 64 * c;
+        v[rr][c] = (j < M && k <= P) ? src[k] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      if (j < M) {   // wave-uniform
+        // segment sums (every lane gets them), tv = their sum in ancestor order
+        double tvj = 0.0;
+        for (int t = 0; t < J; ++t) {
+          double x = 0.0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x += (tk[c] == t) ? v[rr][c] * wk[c] : 0.0;
+          x = wave_allsum(x);
+          if (lane == 0) s_seg[wid][t] = x;
+          tvj += x;
+        }
+        double rj = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c == lastc) rj = __shfl(v[rr][c], lastl, 64);
+        const double sig = rj * rj + tsq[j];
+        if (!(sig > 0.0) && lane == 0) s_fail = 1;
+        const double mu = -rj * tvj + tsq[j] * yx[j];
+        const double cc = 1.0 / sqrt(sig);
+        const double wj = cc * cc * mu + cc * zc[j];
+        if (lane == 0) A.w[G.row0 + j] = wj;
+        const double evj = rj * wj + tvj;
+        // this row's share of the vector records: -N[j][k] (ev_j - seg_t(k)[j])
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (tk[c] >= 0) acc[c] -= v[rr][c] * (evj - s_seg[wid][tk[c]]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) red[wid * 256 + lane + 64 * c] = acc[c];
+  __syncthreads();
+  double *rec = A.acc + B0.acc_off;
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    const int ma = s_am[t], i = k - s_ao[t];
+    double a = ((red[k] + red[256 + k]) + red[512 + k]) + red[768 + k];
+    for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
+    rec[s_aoff[t] + ma * ma + i] = a;
+  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 11);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Phase C: residual + quadratic form per block (spamtree_model.cpp:781-826)
 // ---------------------------------------------------------------------------------------------------------------
 struct LoglikArgs {
@@ -3125,8 +3277,8 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.Mrows = L.Mrows; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
-        // leaf groups keep the staged kernel (nothing latency-bound to hide there: staging wins)
-        if (F.do_gram || h->sample_lean == 0 || !L.isref) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
+        if (F.do_gram || h->sample_lean == 0 || (!L.isref && L.maxP > 255)) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
+        else if (!L.isref) hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
         else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
       } else if (L.big_sample) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
