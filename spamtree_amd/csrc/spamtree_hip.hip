@@ -613,6 +613,48 @@ struct Grp {
   int M, P;
 };
 
+// Group descriptor: everything the per-group kernels used to chase through grps -> blks -> anc_idx -> blks -> dch_idx ->
+// blks, flattened on the host into one fixed-stride record of 64-bit words (one global round trip instead of four):
+//   [0] row0  [1] acc_off  [2] M | P<<32  [3] J | nblk<<32  [4] isref | level<<32  [5] nch | acc_len<<32  [6] blk0
+//   [7] total record length   then per ancestor t: am | ao<<32, first row, panel offset, record offset (4 words)
+//   then per block: panel offset, first row, ld (3 words)   then per direct child holding a record: its acc_off
+#define GD_MAXW 272
+struct GdHead {
+  long long row0, acc_off;
+  int M, P, nanc, nblk, isref, level, ndch, acc_len, blk0;
+};
+__device__ __forceinline__ GdHead gd_unpack(const long long *s_gd, int tid, int *s_am, int *s_ao, long long *s_arow, long long *s_apan,
+                                            long long *s_aoff, long long *s_bpan, long long *s_brow, int *s_bld, long long *s_coff) {
+  GdHead H;
+  // every thread reads the same words: keep the header in scalar registers
+  auto sll = [](long long v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+  };
+  auto slo = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)); };
+  auto shi = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v >> 32)); };
+  H.row0 = sll(s_gd[0]); H.acc_off = sll(s_gd[1]);
+  H.M = slo(s_gd[2]); H.P = shi(s_gd[2]);
+  H.nanc = slo(s_gd[3]); H.nblk = shi(s_gd[3]);
+  H.isref = slo(s_gd[4]); H.level = shi(s_gd[4]);
+  H.ndch = slo(s_gd[5]); H.acc_len = shi(s_gd[5]);
+  H.blk0 = slo(s_gd[6]);
+  if (tid < H.nanc) {
+    const long long *a = s_gd + 8 + 4 * tid;
+    s_am[tid] = (int)(a[0] & 0xffffffffLL); s_ao[tid] = (int)(a[0] >> 32);
+    s_arow[tid] = a[1];
+    if (s_apan) s_apan[tid] = a[2];
+    if (s_aoff) s_aoff[tid] = a[3];
+  }
+  if (tid == 0) { s_ao[H.nanc] = H.P; if (s_aoff) s_aoff[H.nanc] = s_gd[7]; }
+  if (tid >= 64 && tid < 64 + H.nblk) {
+    const long long *b = s_gd + 8 + 4 * H.nanc + 3 * (tid - 64);
+    s_bpan[tid - 64] = b[0]; s_brow[tid - 64] = b[1]; s_bld[tid - 64] = (int)b[2];
+  }
+  if (s_coff && tid >= 128 && tid < 128 + H.ndch) s_coff[tid - 128] = s_gd[8 + 4 * H.nanc + 3 * H.nblk + (tid - 128)];
+  return H;
+}
+
 struct FastArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -1193,6 +1235,8 @@ struct SampleFastArgs {
   const int *mv;
   double *acc;
   int *errflag;
+  const long long *gdesc;   // group descriptors of this launch's first group onwards
+  int gd_stride;
   int ldN, Mr4, Mrows, maxP, av_dbl;   // Mrows: staged panel rows (the level's largest group)   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
   int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
   double tausq_inv[QMAX];
@@ -1207,6 +1251,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   __shared__ int s_fail;
   __shared__ long long s_coff[64];               // message records of the direct children
   __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -1224,37 +1269,21 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
     const int per = A.ngrp >> 3;
     if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
   }
-  const Grp G = A.grps[gidx];
-  const int M = G.M, P = G.P;
-  const Blk B0 = A.blks[G.blk0];
-  const int J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
   STAMP_DECL
-  if (tid < J) {
-    const int a = A.anc_idx[B0.anc_ptr + tid];
-    s_am[tid] = A.blks[a].m;
-    s_arow[tid] = A.blks[a].row0;
-  }
-  if (tid >= 64 && tid < 64 + G.nblk) {
-    const Blk Bb = A.blks[G.blk0 + tid - 64];
-    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
-  }
-  if (tid >= 128 && tid < 128 + min(B0.ndch, 64)) s_coff[tid - 128] = A.blks[A.dch_idx[B0.dch_ptr + tid - 128]].acc_off;
-  if (tid == 0) { s_fail = 0; s_nch = min(B0.ndch, 64); }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    long long ao = 0;
-    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
-    s_ao[J] = o; s_aoff[J] = ao;
-  }
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
   if (tid < 32) {
     const int j = tid;
     if (j < M) {
       const long long r = G.row0 + j;
       tsq[j] = A.tausq_inv[A.mv[r]]; yx[j] = A.y[r] - A.xb[r]; zc[j] = A.z[r];
       int bi = 0;
-      while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
+      while (bi + 1 < G.nblk && r >= s_gd[8 + 4 * J + 3 * (bi + 1) + 1]) ++bi;
       colblk[j] = bi;
     } else {
       tsq[j] = 0.0; yx[j] = 0.0; zc[j] = 0.0; colblk[j] = 0;
@@ -1487,7 +1516,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
 // LDS holds vectors only (plus the m x m posterior precision of reference blocks): ~6-19 KB instead of 50-55 KB, so
 // 6-8 workgroups share a CU and their latency chains overlap.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 6) void k_sample_lean(SampleFastArgs A) {
+__global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
@@ -1496,6 +1525,7 @@ __global__ __launch_bounds__(NT, 6) void k_sample_lean(SampleFastArgs A) {
   __shared__ int s_fail;
   __shared__ long long s_coff[64];
   __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
 
   const int tid = threadIdx.x;
   double *wv = lds;                                  // maxP + 32 : ancestors' w, then the group's new w
@@ -1509,28 +1539,13 @@ __global__ __launch_bounds__(NT, 6) void k_sample_lean(SampleFastArgs A) {
     const int per = A.ngrp >> 3;
     if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
   }
-  const Grp G = A.grps[gidx];
-  const int M = G.M, P = G.P;
-  const Blk B0 = A.blks[G.blk0];
-  const int J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
-  if (tid < J) {
-    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + tid]];
-    s_am[tid] = Ba.m; s_arow[tid] = Ba.row0;
-  }
-  if (tid >= 64 && tid < 64 + G.nblk) {
-    const Blk Bb = A.blks[G.blk0 + tid - 64];
-    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
-  }
-  if (tid >= 128 && tid < 128 + min(B0.ndch, 64)) s_coff[tid - 128] = A.blks[A.dch_idx[B0.dch_ptr + tid - 128]].acc_off;
-  if (tid == 0) { s_fail = 0; s_nch = min(B0.ndch, 64); }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    long long ao = 0;
-    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
-    s_ao[J] = o; s_aoff[J] = ao;
-  }
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
   if (tid >= 32 && tid < 64) {
     const int j = tid - 32;
     double t_ = 0.0, y_ = 0.0, z_ = 0.0, r_ = 0.0;
@@ -1539,8 +1554,9 @@ __global__ __launch_bounds__(NT, 6) void k_sample_lean(SampleFastArgs A) {
     if (j < M) {
       const long long r = G.row0 + j;
       t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
-      while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
-      ro = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
+      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
+      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
       if (!refgrp) r_ = A.panels[ro + P];
     }
     tsq[j] = t_; yx[j] = y_; zc[j] = z_; rjv[j] = r_; s_cb[j] = bi; s_rowoff[j] = ro;
@@ -1722,6 +1738,7 @@ __global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
   __shared__ int s_fail;
   __shared__ long long s_coff[64];
   __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
   __shared__ double s_seg[NT / 64][MAXJ];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1734,27 +1751,12 @@ __global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
     const int per = A.ngrp >> 3;
     if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
   }
-  const Grp G = A.grps[gidx];
-  const int M = G.M, P = G.P;
-  const Blk B0 = A.blks[G.blk0];
-  const int J = B0.nanc;
-  if (tid < J) {
-    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + tid]];
-    s_am[tid] = Ba.m; s_arow[tid] = Ba.row0;
-  }
-  if (tid >= 64 && tid < 64 + G.nblk) {
-    const Blk Bb = A.blks[G.blk0 + tid - 64];
-    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
-  }
-  if (tid >= 128 && tid < 128 + min(B0.ndch, 64)) s_coff[tid - 128] = A.blks[A.dch_idx[B0.dch_ptr + tid - 128]].acc_off;
-  if (tid == 0) { s_fail = 0; s_nch = min(B0.ndch, 64); }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    long long ao = 0;
-    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
-    s_ao[J] = o; s_aoff[J] = ao;
-  }
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
   if (tid >= 32 && tid < 64) {
     const int j = tid - 32;
     double t_ = 0.0, y_ = 0.0, z_ = 0.0;
@@ -1763,8 +1765,9 @@ __global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
       const long long r = G.row0 + j;
       t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
       int bi = 0;
-      while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
-      ro = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
+      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
+      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
     }
     tsq[j] = t_; yx[j] = y_; zc[j] = z_; s_rowoff[j] = ro;
   }
@@ -1921,6 +1924,8 @@ struct LoglikGrpArgs {
   const double *w;
   double *loglik_c;
   int maxP;
+  const long long *gdesc;   // all group descriptors (indexed by the absolute group index in `list`)
+  int gd_stride;
 };
 
 __global__ __launch_bounds__(NT, 8) void k_loglik_grp(LoglikGrpArgs A) {
@@ -1930,32 +1935,23 @@ __global__ __launch_bounds__(NT, 8) void k_loglik_grp(LoglikGrpArgs A) {
   __shared__ long long s_bpan[32], s_brow[32];
   __shared__ int s_bld[32], s_cb[32];
   __shared__ double s_e2[32];
+  __shared__ long long s_gd[GD_MAXW];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   double *wv = lds;   // maxP + 32
-  const Grp G = A.grps[A.list[blockIdx.x]];
-  const int M = G.M, P = G.P;
-  const Blk B0 = A.blks[G.blk0];
-  const int J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
-  if (tid < J) {
-    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + tid]];
-    s_am[tid] = Ba.m; s_arow[tid] = Ba.row0;
+  {
+    const long long *gd = A.gdesc + (size_t)A.list[blockIdx.x] * A.gd_stride;
+    for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = gd[i];   // the group's descriptor: one round trip
   }
-  if (tid >= 64 && tid < 64 + G.nblk) {
-    const Blk Bb = A.blks[G.blk0 + tid - 64];
-    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
-  }
-  if (tid >= 128 && tid < 128 + 32) wv[P + tid - 128] = (tid - 128 < M) ? A.w[G.row0 + tid - 128] : 0.0;
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-    s_ao[J] = o;
-  }
-  if (tid >= 64 && tid < 96) {
-    const int j = tid - 64;
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, nullptr, s_bpan, s_brow, s_bld, nullptr);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid >= 128 && tid < 128 + 32) wv[P + tid - 128] = (tid - 128 < M) ? A.w[G.row0 + tid - 128] : 0.0;
+  if (tid >= 32 && tid < 64) {
+    const int j = tid - 32;
     int bi = 0;
-    if (j < M) { const long long r = G.row0 + j; while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi; }
+    if (j < M) { const long long r = G.row0 + j; while (bi + 1 < G.nblk && r >= s_gd[8 + 4 * J + 3 * (bi + 1) + 1]) ++bi; }
     s_cb[j] = bi;
   }
   __syncthreads();
@@ -2168,6 +2164,9 @@ struct st_handle_s {
   DevBuf<Grp> d_grps;
   std::vector<Quad> quads;
   DevBuf<Quad> d_quads;
+  std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
+  DevBuf<long long> d_gdesc;
+  int gd_stride = 8;
   int quad_nu = 4;
   // multi-GPU sharding
   int rank = 0, world = 1, cut = 0;
@@ -2303,7 +2302,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free();
+  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
@@ -2810,6 +2809,42 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   { std::vector<int> a = h->dch_idx; if (a.empty()) a.push_back(0); CCHK(h->d_dch.upload(a)); }
   CCHK(h->d_lvl.upload(h->lvl_list));
   { std::vector<Grp> g = h->grps; if (g.empty()) g.push_back(Grp{0, 0, 0, 0, 0}); CCHK(h->d_grps.upload(g)); }
+  {
+    // group descriptors: the flattened metadata of every column group (layout: GdHead / gd_unpack)
+    int stride = 8;
+    for (const Grp &G : h->grps) {
+      const Blk &B0 = h->blks[G.blk0];
+      stride = std::max(stride, 8 + 4 * B0.nanc + 3 * G.nblk + std::min(B0.ndch, 64));
+    }
+    stride = (stride + 1) & ~1;
+    if (stride > GD_MAXW) return fail_create(h, ST_ERR_UNSUPPORTED, "group descriptor too long");
+    h->gd_stride = stride;
+    h->gdesc.assign(std::max<size_t>(1, h->grps.size()) * (size_t)stride, 0);
+    auto pack = [](long long lo, long long hi) { return (lo & 0xffffffffLL) | (hi << 32); };
+    for (size_t g = 0; g < h->grps.size(); ++g) {
+      const Grp &G = h->grps[g];
+      const Blk &B0 = h->blks[G.blk0];
+      long long *w = h->gdesc.data() + g * (size_t)stride;
+      const int nch = std::min(B0.ndch, 64);
+      w[0] = G.row0; w[1] = B0.acc_off; w[2] = pack(G.M, G.P); w[3] = pack(B0.nanc, G.nblk); w[4] = pack(B0.isref, B0.level);
+      w[5] = pack(nch, B0.acc_len); w[6] = pack(G.blk0, 0);
+      long long ao = 0, aoff = 0;
+      for (int t = 0; t < B0.nanc; ++t) {
+        const Blk &Ba = h->blks[h->anc_idx[B0.anc_ptr + t]];
+        long long *a = w + 8 + 4 * t;
+        a[0] = pack(Ba.m, ao); a[1] = Ba.row0; a[2] = Ba.panel_off; a[3] = aoff;
+        ao += Ba.m; aoff += (long long)Ba.m * Ba.m + Ba.m;
+      }
+      w[7] = aoff;
+      for (int b = 0; b < G.nblk; ++b) {
+        const Blk &Bb = h->blks[G.blk0 + b];
+        long long *q = w + 8 + 4 * B0.nanc + 3 * b;
+        q[0] = Bb.panel_off; q[1] = Bb.row0; q[2] = Bb.ld;
+      }
+      for (int c = 0; c < nch; ++c) w[8 + 4 * B0.nanc + 3 * G.nblk + c] = h->blks[h->dch_idx[B0.dch_ptr + c]].acc_off;
+    }
+    CCHK(h->d_gdesc.upload(h->gdesc));
+  }
   { std::vector<Quad> g = h->quads; if (g.empty()) g.push_back(Quad{0, 0, 0, 0}); CCHK(h->d_quads.upload(g)); }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
@@ -3276,6 +3311,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.Mrows = L.Mrows; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
+        F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
         if (F.do_gram || h->sample_lean == 0 || (!L.isref && L.maxP > 255)) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
         else if (!L.isref) hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
@@ -3389,6 +3425,7 @@ extern "C" int st_loglik_local(st_handle h, int slot) {
       LoglikGrpArgs Gr;
       Gr.blks = h->d_blks.p; Gr.anc_idx = h->d_anc.p; Gr.grps = h->d_grps.p; Gr.list = h->d_owngrp.p; Gr.nlist = (int)h->own_grp_list.size();
       Gr.panels = h->d_panels[phys].p; Gr.w = h->d_w.p; Gr.loglik_c = h->d_loglik[phys].p; Gr.maxP = maxP;
+      Gr.gdesc = h->d_gdesc.p; Gr.gd_stride = h->gd_stride;
       hipLaunchKernelGGL(k_loglik_grp, dim3(Gr.nlist), dim3(NT), (size_t)(maxP + 32) * sizeof(double), h->stream, Gr);
     }
   }
