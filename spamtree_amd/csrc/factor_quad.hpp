@@ -34,6 +34,8 @@ struct QuadArgs {
   double *panels;
   double *logdet_c, *loglik_c;
   int *errflag;
+  const long long *gdesc;   // group descriptors of the level's first group onwards (Quad::g0 is relative to it)
+  int gd_stride;
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
 };
 
@@ -161,49 +163,62 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   const Quad Q = A.quads[qidx];
   const int Jc = Q.Jc, Pc = Q.Pc, nu = Q.nu;
 
-  // ---- topology of the quad
+  // ---- topology of the quad: the units' group descriptors (layout: GdHead) land in the arena, which is free until the
+  // covariance pass -- one round trip instead of the grps -> blks -> anc_idx -> blks chain
+  long long *gdl = (long long *)arena;   // [nu][gd_stride]
+  const int gds = A.gd_stride;
+  for (int e = tid; e < nu * gds; e += NTQ) {
+    const int uu = e / gds, i = e - uu * gds;
+    gdl[e] = A.gdesc[(size_t)(Q.g0 + uu) * gds + i];
+  }
+  for (int k = tid; k < ldS; k += NTQ) zrow[k] = 0.0;
+  __syncthreads();
   if (tid < NU) {
     int M = 0, P = 0, blk0 = 0, nblk = 0, isref = 0, J = 0, pm = 0;
     long long row0 = 0, prow = 0, ppan = 0;
     if (tid < nu) {
-      const Grp G = A.grps[Q.g0 + tid];
-      const Blk B0 = A.blks[G.blk0];
-      M = G.M; P = G.P; blk0 = G.blk0; nblk = G.nblk; row0 = G.row0; isref = B0.isref; J = B0.nanc;
-      if (tid == 0) s_level = B0.level;
-      if (B0.nanc > Jc) {
-        const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + Jc]];
-        pm = Ba.m; prow = Ba.row0; ppan = Ba.panel_off;
+      const long long *g = gdl + (size_t)tid * gds;
+      row0 = g[0];
+      M = (int)(g[2] & 0xffffffffLL); P = (int)(g[2] >> 32);
+      J = (int)(g[3] & 0xffffffffLL); nblk = (int)(g[3] >> 32);
+      isref = (int)(g[4] & 0xffffffffLL);
+      blk0 = (int)(g[6] & 0xffffffffLL);
+      if (tid == 0) s_level = (int)(g[4] >> 32);
+      if (J > Jc) {   // the private (last) ancestor
+        const long long *a = g + 8 + 4 * Jc;
+        pm = (int)(a[0] & 0xffffffffLL); prow = a[1]; ppan = a[2];
       }
     }
     s_uM[tid] = M; s_uP[tid] = P; s_ublk0[tid] = blk0; s_unblk[tid] = nblk; s_uref[tid] = isref; s_uJ[tid] = J;
     s_pm[tid] = pm; s_urow0[tid] = row0; s_prow[tid] = prow; s_ppan[tid] = ppan; s_fail[tid] = 0;
   }
-  if (tid >= 64 && tid < 64 + Jc) {
+  if (tid >= 64 && tid < 64 + Jc) {   // the shared chain: the first Jc ancestors of unit 0
     const int t = tid - 64;
-    const Blk B0 = A.blks[A.grps[Q.g0].blk0];
-    const Blk Ba = A.blks[A.anc_idx[B0.anc_ptr + t]];
-    s_am[t] = Ba.m; s_arow[t] = Ba.row0; s_apan[t] = Ba.panel_off;
+    const long long *a = gdl + 8 + 4 * t;
+    s_am[t] = (int)(a[0] & 0xffffffffLL); s_ao[t] = (int)(a[0] >> 32); s_arow[t] = a[1]; s_apan[t] = a[2];
   }
-  for (int k = tid; k < ldS; k += NTQ) zrow[k] = 0.0;
-  __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    for (int t = 0; t < Jc; ++t) { s_ao[t] = o; o += s_am[t]; }
-    s_ao[Jc] = o;
+  if (tid == 32) {
+    s_ao[Jc] = Pc;
     // the staged panels of the shared chain in processing order (last ancestor first)
     int n = 0;
     for (int t = Jc - 1; t >= 0; --t) {
+      const long long *a = gdl + 8 + 4 * t;
+      const int ma = (int)(a[0] & 0xffffffffLL), oa = (int)(a[0] >> 32);
       SubIt it;
-      it.geo = s_am[t]; it.Kb = s_ao[t] + s_am[t]; it.pend = 0; it.pad = 0; it.src = s_apan[t]; it.pad2 = 0;
+      it.geo = ma; it.Kb = oa + ma; it.pend = 0; it.pad = 0; it.src = a[2]; it.pad2 = 0;
       s_it[n++] = it;
     }
     s_nit = n;
   }
   for (int e = tid; e < NU * NB; e += NTQ) {
     const int uu = e / NB, b = e - uu * NB;
-    if (b < s_unblk[uu]) {
-      const Blk Bb = A.blks[s_ublk0[uu] + b];
-      s_bpan[uu][b] = Bb.panel_off; s_brow[uu][b] = Bb.row0; s_bld[uu][b] = Bb.ld;
+    if (uu < nu) {
+      const long long *g = gdl + (size_t)uu * gds;
+      const int J = (int)(g[3] & 0xffffffffLL), nblk = (int)(g[3] >> 32);
+      if (b < nblk) {
+        const long long *q = g + 8 + 4 * J + 3 * b;
+        s_bpan[uu][b] = q[0]; s_brow[uu][b] = q[1]; s_bld[uu][b] = (int)q[2];
+      }
     }
   }
   __syncthreads();

@@ -3119,6 +3119,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         F.quads = h->d_quads.p + L.quad_first + L.qown_lo; F.nquad = L.qown_n;
         F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
         F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p; F.ldS = L.q_ldS;
+        F.gdesc = h->d_gdesc.p + (size_t)L.grp_first * h->gd_stride; F.gd_stride = h->gd_stride;
 #define QLAUNCH(NU_, NKX_, NKT_)                                                                                               \
   do {                                                                                                                         \
     if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp); \
