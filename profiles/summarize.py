@@ -19,7 +19,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def family(name):
-    for f in ("k_factor_quad", "k_factor_mfma", "k_factor", "k_sample_mfma", "k_sample", "k_loglik_grp", "k_loglik", "k_sum2", "k_stats",
+    for f in ("k_factor_quad", "k_factor_mfma", "k_factor", "k_sample_mfma", "k_sample_lean", "k_sample_leaf", "k_sample", "k_loglik_grp", "k_loglik", "k_sum2", "k_stats",
               "k_xb", "k_normals"):
         if f in name:
             return f
