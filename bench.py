@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--side", type=int, default=1000, help="grid side; n = side^2 (1000 -> config #3, 316 -> #2)")
     ap.add_argument("--q", type=int, default=1)
+    ap.add_argument("--cell-size", type=int, default=25, help="knots per cell (config #5: 9)")
+    ap.add_argument("--missing", type=str, default="", help="per-outcome drop probabilities, e.g. 0.1,0.3,0.5 (config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-side", type=int, default=316, help="grid side of the bounded CPU-baseline sample")
     args = ap.parse_args()
@@ -94,7 +96,8 @@ def main():
     from spamtree_amd.synthetic import make_workload
 
     t_setup = time.time()
-    wl = make_workload(args.side, q=args.q)
+    missing = tuple(float(x) for x in args.missing.split(",")) if args.missing else None
+    wl = make_workload(args.side, q=args.q, cell_size=args.cell_size, missing=missing)
     # N > 1: one problem shared by all ranks -- subtrees below a cut level are owned by one GPU, the top is replicated,
     # exchanges are RCCL all-reduces issued by the library on its own stream (include/spamtree_hip.h, multi-GPU section)
     uid = None
