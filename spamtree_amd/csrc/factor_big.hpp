@@ -1,0 +1,281 @@
+// Included by spamtree_hip.hip after factor_quad.hpp (needs FactorArgs, Blk, CovPar, cov_entry, d4, dma typedefs, chol helpers).
+#pragma once
+
+// Phase A for blocks wider than 32 columns or chains longer than 256 rows (default multivariate trees: 75-row blocks,
+// chains up to 525 rows -- config #4).  Same per-block workgroup, scratch arena and epilogue as k_factor<true, MODE_FACTOR>;
+// the pass over the ancestor chain runs on the FP64 matrix cores:
+//   * 16-row sub-panels of the ancestors' panels staged by LDS-DMA;
+//   * V_sub = Linv_sub K: A from LDS, B straight from K in the workgroup's scratch slice (L2-resident), one column tile per
+//     wave (the fifth tile goes to wave 0);
+//   * T[column][chain] += V_sub' Linv_sub with the accumulators in REGISTERS: wave w owns the chain tiles kt = w, w+4, ...
+//     for all column tiles; 5 x 5 tiles per wave cover 17 chain tiles (272 rows) per pass, so chains up to 544 rows take
+//     two passes -- the second re-stages the panels of the ancestors that reach past row 272 and reads V back from the
+//     scratch slice (V replaced the rows of K it was computed from, as in the generic kernel).
+// M <= 80 columns, P <= 544 rows (host check); anything else stays on k_factor<true, MODE_FACTOR>.
+#define BM_JT 5
+#define BM_KTW 5
+#define BM_KTP 17
+__global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar cp) {
+  extern __shared__ double lds[];
+  __shared__ int s_anc[MAXJ], s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
+  __shared__ int s_fail;
+  __shared__ double s_red[NT / 64];
+  constexpr bool BIG = true;
+  constexpr int MODE = MODE_FACTOR;
+
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int maxP = A.maxP, maxM = A.maxM, maxMa = A.maxMa;
+  const int ldS = A.SR;                  // staged row stride (the host passes it in SR): >= maxP + 24, 2 * odd
+  // LDS carve
+  double *sx = lds;
+  double *sy = sx + (maxP + maxM);
+  double *wv = sy + (maxP + maxM);
+  double *hv = wv + (maxP + maxM);     // maxM
+  double *ev = hv + maxM;              // maxM
+  double *rd = ev + maxM;              // maxM
+  double *stage = rd + maxM;           // 16 * ldS
+  double *zrow = stage + (size_t)16 * ldS;   // ldS zeros
+  double *VpL = zrow + ldS;            // 16 x 80: the current sub-panel's V
+  int *smv = (int *)(VpL + 16 * 80);
+  double *KV, *Tt, *Vp, *R, *Ri;
+  {
+    double *g = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    KV = g; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
+  }
+  for (int i = tid; i < 17 * ldS + 16 * 80; i += NT) stage[i] = 0.0;   // stage, zero row, VpL: never NaN garbage
+  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
+    const int b = A.list[li];
+    const Blk B = A.blks[b];
+    const int m = B.m, P = B.P, J = B.nanc;
+    __syncthreads();
+    if (tid < J) {
+      const int a = A.anc_idx[B.anc_ptr + tid];
+      s_anc[tid] = a;
+      s_am[tid] = A.blks[a].m;
+      s_arow[tid] = A.blks[a].row0;
+      s_apan[tid] = A.blks[a].panel_off;
+    }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+      s_ao[J] = o;
+    }
+    __syncthreads();
+    for (int t = 0; t < J; ++t) {
+      const long long r0 = s_arow[t];
+      const int oa = s_ao[t];
+      for (int i = tid; i < s_am[t]; i += NT) {
+        sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i];
+      }
+    }
+    for (int i = tid; i < m; i += NT) {
+      sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
+    }
+    __syncthreads();
+    // K_{pa,u}  (covariance_functions.cpp:95-111 / :213-286), T = 0
+    for (int idx = tid; idx < P * m; idx += NT) {
+      const int k = idx / m, j = idx - k * m;
+      KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
+    }
+    __syncthreads();
+    // ---- the ancestor chain on the matrix cores
+    const int JT = (m + 15) >> 4;
+    const int npass = P > 16 * BM_KTP ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+      d4 tacc[BM_JT][BM_KTW];
+#pragma unroll
+      for (int a = 0; a < BM_JT; ++a)
+#pragma unroll
+        for (int c = 0; c < BM_KTW; ++c) tacc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+      const int kt0 = pass * BM_KTP;
+      for (int t = J - 1; t >= 0; --t) {
+        const int ma = s_am[t], oa = s_ao[t], Kb = oa + ma;
+        if (Kb <= 16 * kt0) continue;   // second pass: this ancestor does not reach the upper chain tiles (uniform)
+        const double *pa = A.panels + s_apan[t];
+        for (int r0 = 0; r0 < ma; r0 += 16) {
+          const int sr = min(16, ma - r0);
+          __syncthreads();   // everyone is done with the previous sub-panel's stage / VpL
+          // stage rows r0 .. r0+sr-1 (wave w: rows w, w+4, ...) by LDS-DMA, 128 doubles per piece
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = wid + 4 * rr;
+            if (row < sr) {
+              const double *src = pa + (size_t)(r0 + row) * Kb;
+              for (int c = 0; 128 * c < Kb; ++c)
+                if (128 * c + 2 * lane < Kb)
+                  __builtin_amdgcn_global_load_lds((q_glb_void *)(src + 128 * c + 2 * lane), (q_lds_void *)(stage + (size_t)row * ldS + 128 * c), 16, 0, 0);
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = wid + 4 * rr;
+            if (lane < 20) stage[(size_t)row * ldS + Kb + lane] = 0.0;   // K-step / tile overshoot reads zeros
+          }
+          if (pass == 1) {   // V of this sub-panel comes back from the scratch slice (it replaced K's rows oa ..)
+            for (int idx = tid; idx < 16 * 80; idx += NT) {
+              const int i = idx / 80, j = idx - i * 80;
+              VpL[idx] = (i < sr && j < m) ? KV[(size_t)(oa + r0 + i) * m + j] : 0.0;
+            }
+          }
+          __syncthreads();
+          if (pass == 0) {
+            // V_sub = Linv_sub[:, 0:Kb] K[0:Kb, :]: column tile jt = wid (+ 4)
+            const int ns = (Kb + 3) >> 2;
+            const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + l4;
+            for (int jt = wid; jt < JT; jt += 4) {
+              const int j = jt * 16 + l15;
+              const bool jok = j < m;
+              const double *bp = KV + (size_t)l4 * m + min(j, m - 1);
+              d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+              int st = 0;
+              for (; st + 4 <= ns; st += 4) {
+                double a4[4], b4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  a4[q] = ap[4 * (st + q)];
+                  const int k = 4 * (st + q) + l4;
+                  b4[q] = (jok && k < Kb) ? bp[(size_t)4 * (st + q) * m] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
+              }
+              for (; st < ns; ++st) {
+                const int k = 4 * st + l4;
+                const double b1 = (jok && k < Kb) ? bp[(size_t)4 * st * m] : 0.0;
+                p = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * st], b1, p, 0, 0, 0);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = l4 + 4 * r;
+                VpL[i * 80 + jt * 16 + l15] = p[r];
+                if (i < sr && jok) Vp[(size_t)(r0 + i) * m + j] = p[r];
+              }
+            }
+            __syncthreads();
+          }
+          // T[column tile jt][chain tile kt] += V_sub' Linv_sub for this wave's chain tiles kt = kt0 + wid + 4 c
+          {
+            const int nst = (sr + 3) >> 2;
+#pragma unroll
+            for (int c = 0; c < BM_KTW; ++c) {
+              const int kt = kt0 + wid + 4 * c;
+              if (wid + 4 * c < BM_KTP && kt * 16 < Kb) {
+                const double *b0 = stage + (size_t)l4 * ldS + kt * 16 + l15;
+#pragma unroll
+                for (int a = 0; a < BM_JT; ++a) {
+                  if (a < JT) {
+                    const double *a0 = VpL + l4 * 80 + a * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      if (r < nst) tacc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[4 * r * 80], b0[(size_t)4 * r * ldS], tacc[a][c], 0, 0, 0);
+                  }
+                }
+              }
+            }
+          }
+        }
+        if (pass == 0) {   // the ancestor's V rows replace the K rows they were computed from
+          __syncthreads();
+          for (int idx = tid; idx < ma * m; idx += NT) KV[(size_t)oa * m + idx] = Vp[idx];
+        }
+      }
+      // this pass's T tiles -> the scratch slice (the epilogue reads T from there)
+#pragma unroll
+      for (int c = 0; c < BM_KTW; ++c) {
+        const int kt = kt0 + wid + 4 * c;
+        if (wid + 4 * c < BM_KTP) {
+#pragma unroll
+          for (int a = 0; a < BM_JT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = a * 16 + l4 + 4 * r, k = kt * 16 + l15;
+              if (j < m && k < P) Tt[(size_t)j * P + k] = tacc[a][c][r];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // hv = H w_pa  (wave per row)
+    {
+      const int lane = tid & 63, wid = tid >> 6;
+      for (int j = wid; j < m; j += NT / 64) {
+        double acc = 0.0;
+        for (int k = lane; k < P; k += 64) acc += Tt[j * P + k] * wv[k];
+        acc = wave_sum(acc);
+        if (lane == 0) hv[j] = acc;
+      }
+    }
+    __syncthreads();
+
+    double *pu = A.panels + B.panel_off;
+    const int ld = B.ld;
+    double wcore_part = 0.0, logdet_part = 0.0;
+    if (B.isref) {
+      // R = K_uu - V'V  (lower), chol, inverse
+      for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        if (j <= i) {
+          double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]);
+          for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + j];
+          R[idx] = acc;
+        } else {
+          R[idx] = 0.0;
+        }
+      }
+      chol_lower_inplace(R, m, &s_fail);
+      tri_inverse_lower(R, Ri, m);
+      // panel_u = [ -Ri*T | Ri ]
+      for (int idx = tid; idx < m * P; idx += NT) {
+        const int i = idx / P, k = idx - i * P;
+        double acc = 0.0;
+        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * Tt[j * P + k];
+        pu[(size_t)i * ld + k] = -acc;
+      }
+      for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        pu[(size_t)i * ld + P + j] = Ri[idx];
+      }
+      // e = Ri (w_u - H w_pa)
+      for (int i = tid; i < m; i += NT) {
+        double acc = 0.0;
+        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * (wv[P + j] - hv[j]);
+        wcore_part += acc * acc;
+        logdet_part += log(Ri[i * m + i]);
+      }
+    } else {
+      // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963)
+      for (int i = tid; i < m; i += NT) {
+        double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
+        for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + i];
+        if (!(acc > 0.0)) s_fail = 1;
+        const double r = 1.0 / sqrt(acc);
+        rd[i] = r;
+        pu[(size_t)i * ld + P] = r;
+        const double e = r * (wv[P + i] - hv[i]);
+        wcore_part += e * e;
+        logdet_part += log(r);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < m * P; idx += NT) {
+        const int i = idx / P, k = idx - i * P;
+        pu[(size_t)i * ld + k] = -rd[i] * Tt[idx];
+      }
+    }
+    const double wcore = block_sum(wcore_part, s_red);
+    const double logdet = block_sum(logdet_part, s_red);
+    __syncthreads();
+    if (tid == 0) {
+      A.logdet_c[b] = logdet;
+      A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
+      if (s_fail) atomicMin(A.errflag, B.level * 16 + (J == 0 ? 1 : (B.isref ? 2 : 3)));
+    }
+  }
+}
+
+

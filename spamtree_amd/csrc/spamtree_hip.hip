@@ -1030,6 +1030,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 
 
 #include "factor_quad.hpp"
+#include "factor_big.hpp"
 
 struct SampleArgs {
   const Blk *blks;
@@ -2140,6 +2141,9 @@ struct LevelInfo {
   size_t lds_fast = 0;
   int ldN = 2, Mr4 = 4, Mrows = 1, av_dbl = 224;
   size_t lds_sfast = 0, lds_slean = 0;
+  bool bigmfma = false;            // generic level whose phase A takes k_factor_bigmfma
+  int bm_ldS = 0;
+  size_t lds_bigmfma = 0;
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
   int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
@@ -2629,6 +2633,13 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       }
       L.fast = ok;
       if (!ok) { h->grps.resize(L.grp_first); L.grp_count = 0; }
+      if (!ok && !h->force_generic && L.maxM <= 80 && L.maxP <= 16 * 2 * BM_KTP && L.maxP > 0) {
+        int ldS = L.maxP + 24;
+        while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
+        L.bm_ldS = ldS;
+        L.lds_bigmfma = ((size_t)3 * (L.maxP + L.maxM) + 3 * (size_t)L.maxM + (size_t)17 * ldS + 16 * 80) * 8 + (size_t)((L.maxP + L.maxM + 1) & ~1) * 4 + 64;
+        L.bigmfma = L.lds_bigmfma <= h->lds_limit;
+      }
     }
     if (L.lds_factor > h->lds_limit || L.lds_sample > h->lds_limit || L.lds_loglik > h->lds_limit)
       return fail_create(h, ST_ERR_UNSUPPORTED, "block too large for the LDS-resident vectors");
@@ -2881,7 +2892,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   {
     size_t need = 0;
     auto upd = [&](const LevelInfo &L) {
-      if (L.big_factor) need = std::max(need, scratch_factor_doubles(L.maxP, L.maxM, L.maxMa));
+      if (L.big_factor || L.bigmfma) need = std::max(need, scratch_factor_doubles(L.maxP, L.maxM, L.maxMa));
       if (L.big_sample) need = std::max(need, (size_t)L.maxM * L.maxM);
     };
     for (auto &L : h->levels) upd(L);
@@ -2902,6 +2913,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
     // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
@@ -3135,6 +3147,9 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p;
         F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, h->stream, F, cp);
+      } else if (L.bigmfma && h->factor_gen == 3) {
+        A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
+        hipLaunchKernelGGL(k_factor_bigmfma, dim3(std::min(A.nlist, h->sm_count)), dim3(NT), L.lds_bigmfma, h->stream, A, cp);
       } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
       else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
     }
