@@ -35,21 +35,23 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
   double *hv = wv + (maxP + maxM);     // maxM
   double *ev = hv + maxM;              // maxM
   double *rd = ev + maxM;              // maxM
-  double *stage = rd + maxM;           // 16 * ldS
+  double *stage = rd + maxM;           // 16 * ldS (+ zrow + VpL >= 2 maxM^2 doubles: the epilogue factorises there)
   double *zrow = stage + (size_t)16 * ldS;   // ldS zeros
   double *VpL = zrow + ldS;            // 16 x 80: the current sub-panel's V
-  int *smv = (int *)(VpL + 16 * 80);
+  const size_t work = max((size_t)17 * ldS + 16 * 80, (size_t)2 * maxM * maxM + 64);   // the epilogue's R, Ri overlay stage .. VpL
+  int *smv = (int *)(stage + work);
   double *KV, *Tt, *Vp, *R, *Ri;
   {
     double *g = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
     KV = g; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
   }
-  for (int i = tid; i < 17 * ldS + 16 * 80; i += NT) stage[i] = 0.0;   // stage, zero row, VpL: never NaN garbage
+  for (int i = tid; i < (int)work; i += NT) stage[i] = 0.0;   // stage, zero row, VpL: never NaN garbage
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
     const int b = A.list[li];
     const Blk B = A.blks[b];
     const int m = B.m, P = B.P, J = B.nanc;
     __syncthreads();
+    for (int i = tid; i < ldS + 16 * 80; i += NT) zrow[i] = 0.0;   // the previous block's epilogue wrote over the zero row and the V tile
     if (tid < J) {
       const int a = A.anc_idx[B.anc_ptr + tid];
       s_anc[tid] = a;
@@ -133,6 +135,18 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
               const double *bp = KV + (size_t)l4 * m + min(j, m - 1);
               d4 p = (d4){0.0, 0.0, 0.0, 0.0};
               int st = 0;
+              for (; st + 12 <= ns; st += 12) {   // twelve B operands (L2) in flight per lane
+                double a4[12], b4[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                  const int k = 4 * (st + q) + l4;
+                  b4[q] = (jok && k < Kb) ? bp[(size_t)4 * (st + q) * m] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 12; ++q) a4[q] = ap[4 * (st + q)];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
+              }
               for (; st + 4 <= ns; st += 4) {
                 double a4[4], b4[4];
 #pragma unroll
@@ -217,42 +231,93 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
     const int ld = B.ld;
     double wcore_part = 0.0, logdet_part = 0.0;
     if (B.isref) {
-      // R = K_uu - V'V  (lower), chol, inverse
-      for (int idx = tid; idx < m * m; idx += NT) {
-        const int i = idx / m, j = idx - i * m;
-        if (j <= i) {
-          double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]);
-          for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + j];
-          R[idx] = acc;
-        } else {
-          R[idx] = 0.0;
+      // R = K_uu - V'V (lower) on the matrix cores: both operands are columns of V in the scratch slice; the m x m
+      // factorisation and inversion run in LDS (the stage area is free now), not in the scratch slice
+      double *Rl = stage, *Ril = stage + (size_t)m * m;
+      for (int idx = tid; idx < m * m; idx += NT) Rl[idx] = 0.0;
+      __syncthreads();
+      {
+        const int ns = (P + 3) >> 2;
+        for (int e = wid; e < JT * (JT + 1) / 2; e += NT / 64) {
+          int it = 0;
+          while ((it + 1) * (it + 2) / 2 <= e) ++it;
+          const int jt = e - it * (it + 1) / 2;
+          const int ci = it * 16 + l15, cj = jt * 16 + l15;
+          const double *ap = KV + (size_t)l4 * m + min(ci, m - 1), *bp = KV + (size_t)l4 * m + min(cj, m - 1);
+          d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+          int st = 0;
+          for (; st + 4 <= ns; st += 4) {
+            double a4[4], b4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const bool kok = 4 * (st + q) + l4 < P;
+              a4[q] = (kok && ci < m) ? ap[(size_t)4 * (st + q) * m] : 0.0;
+              b4[q] = (kok && cj < m) ? bp[(size_t)4 * (st + q) * m] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
+          }
+          for (; st < ns; ++st) {
+            const bool kok = 4 * st + l4 < P;
+            const double a1 = (kok && ci < m) ? ap[(size_t)4 * st * m] : 0.0, b1 = (kok && cj < m) ? bp[(size_t)4 * st * m] : 0.0;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+            if (i < m && j <= i) Rl[i * m + j] = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]) - c[r];
+          }
         }
       }
-      chol_lower_inplace(R, m, &s_fail);
-      tri_inverse_lower(R, Ri, m);
-      // panel_u = [ -Ri*T | Ri ]
-      for (int idx = tid; idx < m * P; idx += NT) {
-        const int i = idx / P, k = idx - i * P;
-        double acc = 0.0;
-        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * Tt[j * P + k];
-        pu[(size_t)i * ld + k] = -acc;
+      __syncthreads();
+      chol_lower_inplace(Rl, m, &s_fail);
+      tri_inverse_lower(Rl, Ril, m);
+      // panel_u = [ -Ri*T | Ri ]: tiles (row tile it, chain tile kt), A = -Ri from LDS, B = T from the scratch slice
+      {
+        const int nkt = (P + 15) >> 4;
+        for (int e = wid; e < JT * nkt; e += NT / 64) {
+          const int it = e % JT, kt = e / JT;
+          const int ia = it * 16 + l15, kb = kt * 16 + l15;
+          const int njs = (min(m, it * 16 + 16) + 3) >> 2;
+          d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+          for (int st = 0; st < njs; ++st) {
+            const int j = 4 * st + l4;
+            const double a1 = (ia < m && j <= ia) ? -Ril[ia * m + j] : 0.0;
+            const double b1 = (j < m && kb < P) ? Tt[(size_t)j * P + kb] : 0.0;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + l4 + 4 * r;
+            if (i < m && kb < P) pu[(size_t)i * ld + kb] = c[r];
+          }
+        }
       }
       for (int idx = tid; idx < m * m; idx += NT) {
         const int i = idx / m, j = idx - i * m;
-        pu[(size_t)i * ld + P + j] = Ri[idx];
+        pu[(size_t)i * ld + P + j] = (j <= i) ? Ril[idx] : 0.0;
       }
       // e = Ri (w_u - H w_pa)
       for (int i = tid; i < m; i += NT) {
         double acc = 0.0;
-        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * (wv[P + j] - hv[j]);
+        for (int j = 0; j <= i; ++j) acc += Ril[i * m + j] * (wv[P + j] - hv[j]);
         wcore_part += acc * acc;
-        logdet_part += log(Ri[i * m + i]);
+        logdet_part += log(Ril[i * m + i]);
       }
     } else {
-      // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963)
+      // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963).  sum_k V[k][i]^2 in four
+      // interleaved partial sums per column (stage area), added in a fixed order
+      double *part4 = stage;   // 4 x 128
+      for (int i = tid & 63; i < m; i += 64) {
+        const int q = tid >> 6;
+        double acc = 0.0;
+        for (int k = q; k < P; k += 4) { const double v = KV[(size_t)k * m + i]; acc += v * v; }
+        part4[q * 128 + i] = acc;
+      }
+      __syncthreads();
       for (int i = tid; i < m; i += NT) {
         double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
-        for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + i];
+        acc -= ((part4[i] + part4[128 + i]) + part4[256 + i]) + part4[384 + i];
         if (!(acc > 0.0)) s_fail = 1;
         const double r = 1.0 / sqrt(acc);
         rd[i] = r;

@@ -274,3 +274,32 @@ def test_factor_kernel_generations(case, gen, monkeypatch):
     om.gibbs_sample_w(z); hm.deal_with_w(z)
     assert relerr(hm.get_w()[om.na_ix_all], om.w[om.na_ix_all]) <= REL
     hm.close()
+
+
+def test_big_block_kernel_two_passes():
+    """k_factor_bigmfma on the default multivariate tree (q = 3: 75-row blocks) deep enough for chains of 294 rows, i.e.
+    both passes over the chain (chain tiles 0-16 and 17-..): factors against the oracle and against the generic kernels."""
+    pb = make_problem(side=50, q=3, seed=3)
+    rng = np.random.default_rng(2)
+    w0 = rng.standard_normal(pb["n"])
+    om = oracle_model(pb, w=w0, tausq=0.2)
+    hm = hip_model(pb, w=w0, tausq=0.2)
+    hg = hip_model(pb, w=w0, tausq=0.2, force_generic=True)
+    assert om.get_loglik_comps_w(om.param_data) and hm.get_loglik_comps_w(0) and hg.get_loglik_comps_w(0)
+    assert max(om.parents_indexing[u].size for u in range(om.n_blocks)) > 272
+    assert abs(hm.loglik_w[0] - om.param_data.loglik_w) <= REL * abs(om.param_data.loglik_w)
+    assert abs(hm.loglik_w[0] - hg.loglik_w[0]) <= REL * abs(hg.loglik_w[0])
+    ld, ll = hm.comps(0)
+    assert relerr(ld, om.param_data.logdetCi_comps) <= REL and relerr(ll, om.param_data.loglik_w_comps) <= REL
+    for u in range(om.n_blocks):
+        if om.block_ct_obs[u] == 0:
+            continue
+        H, Ri = hm.block(0, u)
+        if om.parents[u].size:
+            assert relerr(H, om.param_data.w_cond_mean_K[u]) <= 1e-8, u
+        ref_ri = om.param_data.Rcc_invchol[u] if om.block_is_reference[u] else om.param_data.ccholprecdiag[u]
+        assert relerr(Ri, ref_ri) <= REL, u
+    z = rng.standard_normal(pb["n"])
+    om.gibbs_sample_w(z); hm.deal_with_w(z)
+    assert relerr(hm.get_w()[om.na_ix_all], om.w[om.na_ix_all]) <= REL
+    hm.close(); hg.close()
