@@ -12,9 +12,11 @@
 //     two passes -- the second re-stages the panels of the ancestors that reach past row 272 and reads V back from the
 //     scratch slice (V replaced the rows of K it was computed from, as in the generic kernel).
 // M <= 80 columns, P <= 544 rows (host check); anything else stays on k_factor<true, MODE_FACTOR>.
-#define BM_JT 5
-#define BM_KTW 5
-#define BM_KTP 17
+#define BM_MAXP 544
+// BM_JT column tiles x BM_KTW chain tiles per wave in registers; BM_KTP = 4 BM_KTW (rounded down to what is used) chain
+// tiles per pass: <5, 5, 17> for blocks up to 80 columns (two passes beyond 272 rows), <3, 9, 33> for blocks up to 48
+// columns (the leaves of the default multivariate tree: one pass up to 528 rows).
+template <int BM_JT, int BM_KTW, int BM_KTP>
 __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar cp) {
   extern __shared__ double lds[];
   __shared__ int s_anc[MAXJ], s_am[MAXJ], s_ao[MAXJ + 1];

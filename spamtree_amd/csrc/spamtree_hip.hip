@@ -2633,7 +2633,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       }
       L.fast = ok;
       if (!ok) { h->grps.resize(L.grp_first); L.grp_count = 0; }
-      if (!ok && !h->force_generic && L.maxM <= 80 && L.maxP <= 16 * 2 * BM_KTP && L.maxP > 0) {
+      if (!ok && !h->force_generic && L.maxM <= 80 && L.maxP <= BM_MAXP && L.maxP > 0) {
         int ldS = L.maxP + 24;
         while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
         L.bm_ldS = ldS;
@@ -2914,7 +2914,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<5, 5, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 9, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
     // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
@@ -3150,7 +3151,8 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, h->stream, F, cp);
       } else if (L.bigmfma && h->factor_gen == 3) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
-        hipLaunchKernelGGL(k_factor_bigmfma, dim3(std::min(A.nlist, h->sm_count)), dim3(NT), L.lds_bigmfma, h->stream, A, cp);
+        if (L.maxM <= 48 && L.maxP <= 528) hipLaunchKernelGGL((k_factor_bigmfma<3, 9, 33>), dim3(std::min(A.nlist, h->sm_count)), dim3(NT), L.lds_bigmfma, h->stream, A, cp);
+        else hipLaunchKernelGGL((k_factor_bigmfma<5, 5, 17>), dim3(std::min(A.nlist, h->sm_count)), dim3(NT), L.lds_bigmfma, h->stream, A, cp);
       } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
       else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
     }
