@@ -7,22 +7,22 @@
 //   * 16-row sub-panels of the ancestors' panels staged by LDS-DMA;
 //   * V_sub = Linv_sub K: A from LDS, B straight from K in the workgroup's scratch slice (L2-resident), one column tile per
 //     wave (the fifth tile goes to wave 0);
-//   * T[column][chain] += V_sub' Linv_sub with the accumulators in REGISTERS: wave w owns the chain tiles kt = w, w+4, ...
-//     for all column tiles; 5 x 5 tiles per wave cover 17 chain tiles (272 rows) per pass, so chains up to 544 rows take
-//     two passes -- the second re-stages the panels of the ancestors that reach past row 272 and reads V back from the
+//   * T[column][chain] += V_sub' Linv_sub with the accumulators in REGISTERS: wave w owns the chain tiles kt = w, w+8, ...
+//     for all column tiles; BM_JT x BM_KTW tiles per wave cover BM_KTP chain tiles per pass, longer chains take two passes -- the second re-stages the panels of the ancestors that reach past the first pass's rows and reads V back from the
 //     scratch slice (V replaced the rows of K it was computed from, as in the generic kernel).
 // M <= 80 columns, P <= 544 rows (host check); anything else stays on k_factor<true, MODE_FACTOR>.
 #define BM_MAXP 544
-// BM_JT column tiles x BM_KTW chain tiles per wave in registers; BM_KTP = 4 BM_KTW (rounded down to what is used) chain
-// tiles per pass: <5, 5, 17> for blocks up to 80 columns (two passes beyond 272 rows), <3, 9, 33> for blocks up to 48
-// columns (the leaves of the default multivariate tree: one pass up to 528 rows).
+#define BM_NT 512   // 8 waves: two per SIMD, so that one wave's LDS-DMA / L2 / LDS waits overlap the other's MFMAs
+// BM_JT column tiles x BM_KTW chain tiles per wave in registers; BM_KTP <= 8 BM_KTW chain tiles per pass: <5, 3, 24> for
+// blocks up to 80 columns (two passes beyond 384 rows), <4, 5, 34> / <3, 5, 34> for blocks up to 64 / 48 columns (the
+// leaves of the default multivariate tree: one pass).
 template <int BM_JT, int BM_KTW, int BM_KTP>
-__global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar cp) {
+__global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPar cp) {
   extern __shared__ double lds[];
   __shared__ int s_anc[MAXJ], s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
   __shared__ int s_fail;
-  __shared__ double s_red[NT / 64];
+  __shared__ double s_red[BM_NT / 64];
   constexpr bool BIG = true;
   constexpr int MODE = MODE_FACTOR;
 
@@ -47,13 +47,13 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
     double *g = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
     KV = g; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
   }
-  for (int i = tid; i < (int)work; i += NT) stage[i] = 0.0;   // stage, zero row, VpL: never NaN garbage
+  for (int i = tid; i < (int)work; i += BM_NT) stage[i] = 0.0;   // stage, zero row, VpL: never NaN garbage
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
     const int b = A.list[li];
     const Blk B = A.blks[b];
     const int m = B.m, P = B.P, J = B.nanc;
     __syncthreads();
-    for (int i = tid; i < ldS + 16 * 80; i += NT) zrow[i] = 0.0;   // the previous block's epilogue wrote over the zero row and the V tile
+    for (int i = tid; i < ldS + 16 * 80; i += BM_NT) zrow[i] = 0.0;   // the previous block's epilogue wrote over the zero row and the V tile
     if (tid < J) {
       const int a = A.anc_idx[B.anc_ptr + tid];
       s_anc[tid] = a;
@@ -72,16 +72,16 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
     for (int t = 0; t < J; ++t) {
       const long long r0 = s_arow[t];
       const int oa = s_ao[t];
-      for (int i = tid; i < s_am[t]; i += NT) {
+      for (int i = tid; i < s_am[t]; i += BM_NT) {
         sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i];
       }
     }
-    for (int i = tid; i < m; i += NT) {
+    for (int i = tid; i < m; i += BM_NT) {
       sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
     }
     __syncthreads();
     // K_{pa,u}  (covariance_functions.cpp:95-111 / :213-286), T = 0
-    for (int idx = tid; idx < P * m; idx += NT) {
+    for (int idx = tid; idx < P * m; idx += BM_NT) {
       const int k = idx / m, j = idx - k * m;
       KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
     }
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
           __syncthreads();   // everyone is done with the previous sub-panel's stage / VpL
           // stage rows r0 .. r0+sr-1 (wave w: rows w, w+4, ...) by LDS-DMA, 128 doubles per piece
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int row = wid + 4 * rr;
+          for (int rr = 0; rr < 16 / (BM_NT / 64); ++rr) {
+            const int row = wid + (BM_NT / 64) * rr;
             if (row < sr) {
               const double *src = pa + (size_t)(r0 + row) * Kb;
               for (int c = 0; 128 * c < Kb; ++c)
@@ -116,12 +116,12 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
           }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int row = wid + 4 * rr;
+          for (int rr = 0; rr < 16 / (BM_NT / 64); ++rr) {
+            const int row = wid + (BM_NT / 64) * rr;
             if (lane < 20) stage[(size_t)row * ldS + Kb + lane] = 0.0;   // K-step / tile overshoot reads zeros
           }
           if (pass == 1) {   // V of this sub-panel comes back from the scratch slice (it replaced K's rows oa ..)
-            for (int idx = tid; idx < 16 * 80; idx += NT) {
+            for (int idx = tid; idx < 16 * 80; idx += BM_NT) {
               const int i = idx / 80, j = idx - i * 80;
               VpL[idx] = (i < sr && j < m) ? KV[(size_t)(oa + r0 + i) * m + j] : 0.0;
             }
@@ -131,23 +131,23 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
             // V_sub = Linv_sub[:, 0:Kb] K[0:Kb, :]: column tile jt = wid (+ 4)
             const int ns = (Kb + 3) >> 2;
             const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + l4;
-            for (int jt = wid; jt < JT; jt += 4) {
+            for (int jt = wid; jt < JT; jt += BM_NT / 64) {
               const int j = jt * 16 + l15;
               const bool jok = j < m;
               const double *bp = KV + (size_t)l4 * m + min(j, m - 1);
               d4 p = (d4){0.0, 0.0, 0.0, 0.0};
               int st = 0;
-              for (; st + 12 <= ns; st += 12) {   // twelve B operands (L2) in flight per lane
-                double a4[12], b4[12];
+              for (; st + 8 <= ns; st += 8) {   // eight B operands (L2) in flight per lane
+                double a4[8], b4[8];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) {
+                for (int q = 0; q < 8; ++q) {
                   const int k = 4 * (st + q) + l4;
                   b4[q] = (jok && k < Kb) ? bp[(size_t)4 * (st + q) * m] : 0.0;
                 }
 #pragma unroll
-                for (int q = 0; q < 12; ++q) a4[q] = ap[4 * (st + q)];
+                for (int q = 0; q < 8; ++q) a4[q] = ap[4 * (st + q)];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
+                for (int q = 0; q < 8; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
               }
               for (; st + 4 <= ns; st += 4) {
                 double a4[4], b4[4];
@@ -174,21 +174,29 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
             }
             __syncthreads();
           }
-          // T[column tile jt][chain tile kt] += V_sub' Linv_sub for this wave's chain tiles kt = kt0 + wid + 4 c
+          // T[column tile jt][chain tile kt] += V_sub' Linv_sub for this wave's chain tiles kt = kt0 + wid + 8 c.  The V
+          // operands (all column tiles, all K-steps) are read once per sub-panel and reused for every chain tile.
           {
             const int nst = (sr + 3) >> 2;
+            double av[BM_JT][4];
+#pragma unroll
+            for (int a = 0; a < BM_JT; ++a)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) av[a][r] = (a < JT) ? VpL[(4 * r + l4) * 80 + a * 16 + l15] : 0.0;
 #pragma unroll
             for (int c = 0; c < BM_KTW; ++c) {
-              const int kt = kt0 + wid + 4 * c;
-              if (wid + 4 * c < BM_KTP && kt * 16 < Kb) {
+              const int kt = kt0 + wid + (BM_NT / 64) * c;
+              if (wid + (BM_NT / 64) * c < BM_KTP && kt * 16 < Kb) {
                 const double *b0 = stage + (size_t)l4 * ldS + kt * 16 + l15;
+                double bv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = b0[(size_t)4 * r * ldS];
 #pragma unroll
                 for (int a = 0; a < BM_JT; ++a) {
                   if (a < JT) {
-                    const double *a0 = VpL + l4 * 80 + a * 16 + l15;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                      if (r < nst) tacc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[4 * r * 80], b0[(size_t)4 * r * ldS], tacc[a][c], 0, 0, 0);
+                      if (r < nst) tacc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][r], bv[r], tacc[a][c], 0, 0, 0);
                   }
                 }
               }
@@ -197,14 +205,14 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
         }
         if (pass == 0) {   // the ancestor's V rows replace the K rows they were computed from
           __syncthreads();
-          for (int idx = tid; idx < ma * m; idx += NT) KV[(size_t)oa * m + idx] = Vp[idx];
+          for (int idx = tid; idx < ma * m; idx += BM_NT) KV[(size_t)oa * m + idx] = Vp[idx];
         }
       }
       // this pass's T tiles -> the scratch slice (the epilogue reads T from there)
 #pragma unroll
       for (int c = 0; c < BM_KTW; ++c) {
-        const int kt = kt0 + wid + 4 * c;
-        if (wid + 4 * c < BM_KTP) {
+        const int kt = kt0 + wid + (BM_NT / 64) * c;
+        if (wid + (BM_NT / 64) * c < BM_KTP) {
 #pragma unroll
           for (int a = 0; a < BM_JT; ++a) {
 #pragma unroll
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
     // hv = H w_pa  (wave per row)
     {
       const int lane = tid & 63, wid = tid >> 6;
-      for (int j = wid; j < m; j += NT / 64) {
+      for (int j = wid; j < m; j += BM_NT / 64) {
         double acc = 0.0;
         for (int k = lane; k < P; k += 64) acc += Tt[j * P + k] * wv[k];
         acc = wave_sum(acc);
@@ -236,11 +244,11 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
       // R = K_uu - V'V (lower) on the matrix cores: both operands are columns of V in the scratch slice; the m x m
       // factorisation and inversion run in LDS (the stage area is free now), not in the scratch slice
       double *Rl = stage, *Ril = stage + (size_t)m * m;
-      for (int idx = tid; idx < m * m; idx += NT) Rl[idx] = 0.0;
+      for (int idx = tid; idx < m * m; idx += BM_NT) Rl[idx] = 0.0;
       __syncthreads();
       {
         const int ns = (P + 3) >> 2;
-        for (int e = wid; e < JT * (JT + 1) / 2; e += NT / 64) {
+        for (int e = wid; e < JT * (JT + 1) / 2; e += BM_NT / 64) {
           int it = 0;
           while ((it + 1) * (it + 2) / 2 <= e) ++it;
           const int jt = e - it * (it + 1) / 2;
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
       // panel_u = [ -Ri*T | Ri ]: tiles (row tile it, chain tile kt), A = -Ri from LDS, B = T from the scratch slice
       {
         const int nkt = (P + 15) >> 4;
-        for (int e = wid; e < JT * nkt; e += NT / 64) {
+        for (int e = wid; e < JT * nkt; e += BM_NT / 64) {
           const int it = e % JT, kt = e / JT;
           const int ia = it * 16 + l15, kb = kt * 16 + l15;
           const int njs = (min(m, it * 16 + 16) + 3) >> 2;
@@ -295,12 +303,12 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
           }
         }
       }
-      for (int idx = tid; idx < m * m; idx += NT) {
+      for (int idx = tid; idx < m * m; idx += BM_NT) {
         const int i = idx / m, j = idx - i * m;
         pu[(size_t)i * ld + P + j] = (j <= i) ? Ril[idx] : 0.0;
       }
       // e = Ri (w_u - H w_pa)
-      for (int i = tid; i < m; i += NT) {
+      for (int i = tid; i < m; i += BM_NT) {
         double acc = 0.0;
         for (int j = 0; j <= i; ++j) acc += Ril[i * m + j] * (wv[P + j] - hv[j]);
         wcore_part += acc * acc;
@@ -309,17 +317,17 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
     } else {
       // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963).  sum_k V[k][i]^2 in four
       // interleaved partial sums per column (stage area), added in a fixed order
-      double *part4 = stage;   // 4 x 128
+      double *part4 = stage;   // (BM_NT / 64) x 128
       for (int i = tid & 63; i < m; i += 64) {
         const int q = tid >> 6;
         double acc = 0.0;
-        for (int k = q; k < P; k += 4) { const double v = KV[(size_t)k * m + i]; acc += v * v; }
+        for (int k = q; k < P; k += BM_NT / 64) { const double v = KV[(size_t)k * m + i]; acc += v * v; }
         part4[q * 128 + i] = acc;
       }
       __syncthreads();
-      for (int i = tid; i < m; i += NT) {
+      for (int i = tid; i < m; i += BM_NT) {
         double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
-        acc -= ((part4[i] + part4[128 + i]) + part4[256 + i]) + part4[384 + i];
+        for (int q = 0; q < BM_NT / 64; ++q) acc -= part4[q * 128 + i];
         if (!(acc > 0.0)) s_fail = 1;
         const double r = 1.0 / sqrt(acc);
         rd[i] = r;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(NT, 1) void k_factor_bigmfma(FactorArgs A, CovPar c
         logdet_part += log(r);
       }
       __syncthreads();
-      for (int idx = tid; idx < m * P; idx += NT) {
+      for (int idx = tid; idx < m * P; idx += BM_NT) {
         const int i = idx / P, k = idx - i * P;
         pu[(size_t)i * ld + k] = -rd[i] * Tt[idx];
       }

@@ -2914,8 +2914,9 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<5, 5, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 9, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<5, 3, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<4, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
     // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
@@ -3151,8 +3152,9 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, h->stream, F, cp);
       } else if (L.bigmfma && h->factor_gen == 3) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
-        if (L.maxM <= 48 && L.maxP <= 528) hipLaunchKernelGGL((k_factor_bigmfma<3, 9, 33>), dim3(std::min(A.nlist, h->sm_count)), dim3(NT), L.lds_bigmfma, h->stream, A, cp);
-        else hipLaunchKernelGGL((k_factor_bigmfma<5, 5, 17>), dim3(std::min(A.nlist, h->sm_count)), dim3(NT), L.lds_bigmfma, h->stream, A, cp);
+        if (L.maxM <= 48) hipLaunchKernelGGL((k_factor_bigmfma<3, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
+        else if (L.maxM <= 64) hipLaunchKernelGGL((k_factor_bigmfma<4, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
+        else hipLaunchKernelGGL((k_factor_bigmfma<5, 3, 24>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
       } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
       else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
     }
