@@ -44,6 +44,9 @@ struct CovPar {
   double ai1[QMAX], ai2[QMAX], phi[QMAX];
   double tmv[3];
   double D[QMAX * QMAX];
+  // per pair of outcomes, filled on the host (finish_covpar): everything of the Apanasovich-Genton form that does not
+  // depend on the distance.  cov = amp exp(-rate h) [+ amp2 exp(-phi[vi] h) where the Dmat entry is exactly zero]
+  double rate[QMAX * QMAX], amp[QMAX * QMAX], amp2[QMAX * QMAX];
 };
 
 struct Blk {
@@ -100,17 +103,34 @@ __device__ __forceinline__ double cov_entry(const CovPar &c, double xi, double y
   const double dx = xi - xj, dy = yi - yj;
   const double h = cov_sqrt(dx * dx + dy * dy);
   if (c.q == 1) return c.ai1[0] * cov_exp(-c.tmv[0] * h);  // cexpcov: sigmasq = ai1(0), phi = thetamv(0)
-  const double v = c.D[vi * c.q + vj];
-  double cb;  // C_base(h, 0, v)
-  if (c.q > 2) {
-    const double ps = exp(0.5 * c.tmv[1] * log1p(c.tmv[0] * v));
-    cb = cov_exp(-c.tmv[2] * (h / ps)) / (ps * ps);
-  } else {
-    const double ps = sqrt(v + 1.0);
-    cb = cov_exp(-c.tmv[0] * (h / ps)) / (v + 1.0);
-  }
-  if (v == 0.0) return c.ai1[vi] * c.ai1[vi] * cb + c.ai2[vi] * c.ai2[vi] * cov_exp(-c.phi[vi] * h);
-  return c.ai1[vi] * c.ai1[vj] * cb;
+  // mvCovAG20107 (covariance_functions.cpp:213-286): C_base(h, 0, v) = exp(-c h / psi) / psi^2 with psi = (a v + 1)^(b/2)
+  // (q > 2) or exp(-c h / sqrt(v + 1)) / (v + 1) (q = 2); psi, the amplitudes and the v == 0 case are per outcome pair
+  const int ij = vi * c.q + vj;
+  double r = c.amp[ij] * cov_exp(-c.rate[ij] * h);
+  const double a2 = c.amp2[ij];
+  if (a2 != 0.0) r += a2 * cov_exp(-c.phi[vi] * h);
+  return r;
+}
+
+// host: the distance-independent parts of the multivariate form
+static void finish_covpar(CovPar *c) {
+  const int q = c->q;
+  for (int vi = 0; vi < q; ++vi)
+    for (int vj = 0; vj < q; ++vj) {
+      const int ij = vi * q + vj;
+      const double v = c->D[ij];
+      double rate, den;
+      if (q > 2) {
+        const double ps = std::exp(0.5 * c->tmv[1] * std::log1p(c->tmv[0] * v));
+        rate = c->tmv[2] / ps; den = ps * ps;
+      } else {
+        const double ps = std::sqrt(v + 1.0);
+        rate = c->tmv[0] / ps; den = v + 1.0;
+      }
+      c->rate[ij] = rate;
+      if (v == 0.0) { c->amp[ij] = c->ai1[vi] * c->ai1[vi] / den; c->amp2[ij] = c->ai2[vi] * c->ai2[vi]; }
+      else { c->amp[ij] = c->ai1[vi] * c->ai1[vj] / den; c->amp2[ij] = 0.0; }
+    }
 }
 
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for global loads in flight
@@ -3056,6 +3076,7 @@ static int make_covpar(st_handle h, const double *theta, int ntheta, CovPar *cp)
   int ix = 0;
   for (int j = 0; j < q; ++j)
     for (int i = j + 1; i < q; ++i) { cp->D[i * q + j] = theta[npars + ix]; cp->D[j * q + i] = theta[npars + ix]; ++ix; }
+  finish_covpar(cp);
   return ST_OK;
 }
 
@@ -3664,6 +3685,7 @@ extern "C" int st_cross_covariance_ag10(const double *coords1, const int64_t *mv
   for (int j = 0; j < q; ++j) { cp.ai1[j] = ai1[j]; cp.ai2[j] = ai2[j]; cp.phi[j] = phi_i[j]; }
   for (int j = 0; j < cp.ncb; ++j) cp.tmv[j] = thetamv[j];
   for (int i = 0; i < q * q; ++i) cp.D[i] = Dmat[i];   // symmetric: layout irrelevant
+  finish_covpar(&cp);
   std::vector<int> m1(n1), m2(n2);
   for (int64_t i = 0; i < n1; ++i) { m1[i] = (int)mv1[i] - 1; if (m1[i] < 0 || m1[i] >= q) { g_create_error = "mv1 out of range"; return ST_ERR_USAGE; } }
   for (int64_t i = 0; i < n2; ++i) { m2[i] = (int)mv2[i] - 1; if (m2[i] < 0 || m2[i] >= q) { g_create_error = "mv2 out of range"; return ST_ERR_USAGE; } }
