@@ -1076,7 +1076,7 @@ template <bool BIG>
 __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
   __shared__ int s_fail;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   double *ev = tv + maxM;              // maxM   Ri w_u + N w_pa
   double *bv = ev + maxM;              // maxM   rhs / solution
   double *av = bv + maxM;              // maxM   per-ancestor temp
-  double *Np = av + maxM;              // !BIG: maxM * maxLd panel copy
+  double *seg = av + maxM;             // MAXJ * maxM: seg[t][r] = sum_j N[r][oa_t + j] w_a[j], later ev[r] - seg[t][r]
+  double *Np = seg + (size_t)MAXJ * maxM;   // !BIG: maxM * maxLd panel copy
   double *S = BIG ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
 
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
@@ -1103,8 +1104,9 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     __syncthreads();
     if (tid == 0) {
       int o = 0;
-      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-      s_ao[J] = o;
+      long long ao = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+      s_ao[J] = o; s_aoff[J] = ao;
     }
     __syncthreads();
     for (int t = 0; t < J; ++t) {
@@ -1205,6 +1207,48 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     }
     __syncthreads();
     // messages to every ancestor (:1158-1207), summed with the direct children's accumulated messages
+    if (!A.do_gram) {
+      // Gram parts cached (Q4): only the vectors.  All ancestors at once, as in k_sample_lean: thread (row r, ancestor t)
+      // sums its segment N[r][oa_t ..] w_a, then thread k (a chain column) accumulates -sum_r N[r][k] (ev[r] - seg_t(k)[r])
+      for (int idx = tid; idx < m * J; idx += NT) {
+        const int r = idx / J, t = idx - r * J;
+        const int ma = s_am[t], oa = s_ao[t];
+        const double *row = N + (size_t)r * ld + oa;
+        const double *wa = wv + oa;
+        double a = 0.0;
+        for (int j0 = 0; j0 < ma; j0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+        }
+        seg[t * maxM + r] = ev[r] - a;
+      }
+      __syncthreads();
+      double *rec = A.acc + B.acc_off;
+      for (int k = tid; k < P; k += NT) {
+        int t = 0;
+        while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+        const int ma = s_am[t], i = k - s_ao[t];
+        const double *avt = seg + t * maxM;
+        double a = 0.0;
+        for (int r0 = 0; r0 < m; r0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < m) ? N[(size_t)(r0 + rr) * ld + k] : 0.0;
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) a -= x[rr] * ((r0 + rr < m) ? avt[r0 + rr] : 0.0);
+        }
+        for (int c = 0; c < B.ndch; ++c) {
+          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
+          a += A.acc[C.acc_off + s_aoff[t] + ma * ma + i];
+        }
+        rec[s_aoff[t] + ma * ma + i] = a;
+      }
+      if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
+      continue;
+    }
     long long off = 0;
     for (int t = 0; t < J; ++t) {
       const int ma = s_am[t], oa = s_ao[t];
@@ -2310,7 +2354,7 @@ static size_t scratch_factor_doubles(int maxP, int maxM, int maxMa) {
   return (size_t)2 * maxP * maxM + (size_t)maxMa * maxM + (size_t)2 * maxM * maxM;
 }
 static size_t lds_sample_bytes(int maxP, int maxM, int maxLd, bool big) {
-  size_t dbl = (size_t)(maxP + maxM) + 4 * (size_t)maxM;
+  size_t dbl = (size_t)(maxP + maxM) + 4 * (size_t)maxM + (size_t)MAXJ * maxM;   // ... + segment sums seg[t][r]
   if (!big) dbl += (size_t)maxM * maxLd + (size_t)maxM * maxM;
   return dbl * 8 + 64;
 }
