@@ -3,14 +3,15 @@
 // A workgroup factorises up to NU "units" at once.  A unit is what k_factor_mfma calls a column group: one reference
 // block, or up to 32 columns of sibling non-reference blocks.  The units of a quad share their ancestor chain, except
 // possibly for the last ancestor ("private" ancestor: leaf groups whose parents are siblings).  The shared chain's
-// inverse-Cholesky panels are staged through LDS ONCE for all units, in 16-row sub-panels, double-buffered, one barrier
-// per sub-panel; per sub-panel every wave has 4x the matrix work of k_factor_mfma between barriers and nothing is
-// exchanged between the waves of the main loop:
+// inverse-Cholesky panels are staged through LDS ONCE for all units: whole panels (<= 32 rows) by LDS-DMA into two
+// buffers, the next panel in flight while the matrix cores work on the current one, one LDS-only barrier per panel;
+// per panel every wave has 4x the matrix work of k_factor_mfma between barriers and nothing is exchanged between the
+// waves of the main loop (the private ancestors' panels: all units side by side, 16 rows at a time, before it):
 //   * wave (u, jt) owns 16 columns of unit u over the WHOLE chain: its K_{pa,u} B operands live in registers (kx),
 //     evaluated once straight from the coordinates; so do its T = H_u accumulators (tacc, tiles [column][chain]);
-//   * V_sub = Linv_sub K (A from LDS, B = kx);  T += V_sub' Linv_sub (the V tile in C layout is the A operand, B from
-//     LDS);  the Schur complement K_uu - V'V is accumulated on the fly (reference units: MFMA on the V tiles, the
-//     off-diagonal tile uses the partner wave's V tile of the previous sub-panel through LDS; leaf units: diagonal only);
+//   * V = Linv_panel K (A from LDS, B = kx; two row tiles per panel);  T += V' Linv_panel (the V tiles in C layout are
+//     the A operand, B from LDS);  the Schur complement K_uu - V'V is accumulated on the fly (reference units: MFMA on the V tiles, the
+//     off-diagonal tile uses the partner wave's V tiles of the previous panel through LDS; leaf units: diagonal only);
 //   * epilogue: NU Cholesky eliminations side by side (team = the unit's two waves, one barrier per pivot for all),
 //     N = -Ri T on the matrix cores with the T tiles as B operands (half of them swapped between the two waves so that
 //     each wave holds all columns for its chain tiles), outputs straight from registers.
