@@ -178,6 +178,7 @@ def main():
                                "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH"
                                + (f"; sharded over {world} GPUs by subtree, RCCL all-reduce exchanges" if world > 1 else ""),
                    "n": int(wl["n"]), "q": args.q, "blocks": int(n_blocks), "levels": int(n_levels),
+                   "mh_accept_ratio": float(chain.state()["accept_ratio"]),
                    "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
                        alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},
         "roofline": {"bound": "hbm", "kernel": "k_factor (phase A: covariance build + chain solve + Cholesky)",
