@@ -40,76 +40,6 @@ struct QuadArgs {
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
 };
 
-// Team elimination [A | I] -> [. | L^{-1}] of an m x m SPD matrix (m <= 32): the workgroup is split into teams of TEAM
-// threads (128, or the whole workgroup), one matrix each; all teams run the same pivot loop (mmax = largest m, uniform) and share its barrier.
-// Every thread keeps EPT elements of the lower triangles of A and of B = I in registers (m (m + 1) <= TEAM * EPT).
-// Per pivot k the team publishes, UNSCALED, column k of A strictly below the diagonal, the pivot d_k itself, and row k
-// of B; everything outside those ranges reads as zero, so the update is the same two instructions for every element
-// at every pivot -- val -= (x1 x2) / d_k with x1 = A[i][k], x2 = A[j][k] or B[k][j] -- with no range tests; rows are
-// scaled by 1 / sqrt(d_i) once at the end.
-//   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).
-//   pub: 224 doubles per team: 2 x 96 published cells ([0,36) column, [36,72) row, [80] pivot, [95] always zero), rsd[32]
-typedef __attribute__((address_space(3))) double q_lds_double;
-template <int EPT, int TEAM = 128>
-__device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
-  const int nA = m * (m + 1) / 2, nE = 2 * nA;
-  double *rsd = pub + 192;
-  for (int i = ttid; i < 192; i += TEAM) pub[i] = 0.0;
-  lds_barrier();   // Am was written by other threads; pub is zero
-  // per element: 32-bit LDS addresses of its two factors and of its publication cell in buffer 0 (buffer 1 = +96
-  // doubles, an immediate offset in the unrolled pivot pair below), the pivot at which it is published, its output slot
-  q_lds_double *p1[EPT], *p2[EPT], *pp[EPT];
-  int khi[EPT], eoff[EPT];
-  double val[EPT];
-  q_lds_double *pub3 = (q_lds_double *)pub;
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) {
-    const int e = ttid + TEAM * r;
-    p1[r] = pub3 + 95; p2[r] = pub3 + 95; pp[r] = pub3 + 94; khi[r] = -1; eoff[r] = -1; val[r] = 0.0;
-    if (e < nE) {
-      const int t = e < nA ? 0 : 1;
-      const int f = e - t * nA;
-      int i = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
-      while (i * (i + 1) / 2 > f) --i;
-      while ((i + 1) * (i + 2) / 2 <= f) ++i;
-      const int j = f - i * (i + 1) / 2;
-      p1[r] = pub3 + i;
-      p2[r] = pub3 + (t == 0 ? j : 36 + j);
-      pp[r] = pub3 + (t == 0 ? (i == j ? 80 : i) : 36 + j);
-      khi[r] = t == 0 ? j : i;
-      eoff[r] = t == 1 ? i * CH_LD + j : -1;
-      val[r] = t == 0 ? Am[i * CH_LD + j] : (i == j ? 1.0 : 0.0);
-    }
-  }
-#define TCH_PIVOT(k_, PAR)                                                                                     \
-  {                                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < EPT; ++r) if ((k_) == khi[r]) pp[r][(PAR) * 96] = val[r];            \
-    if (ttid == 0) { pub3[(PAR) * 96 + (k_)] = 0.0; if ((k_) > 0) pub3[(PAR) * 96 + (k_) - 1] = 0.0; }          \
-    lds_barrier();                                                                                             \
-    if ((k_) < m) {                                                                                            \
-      const double d = pub3[(PAR) * 96 + 80];                                                                  \
-      if (ttid == 0) { if (!(d > 0.0)) *fail = 1; rsd[(k_)] = rsqrt(d); }                                      \
-      double rd = __builtin_amdgcn_rcp(d);                                                                     \
-      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
-      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
-      _Pragma("unroll") for (int r = 0; r < EPT; ++r) {                                                        \
-        const double x1 = p1[r][(PAR) * 96], x2 = p2[r][(PAR) * 96];                                           \
-        val[r] = fma(-(x1 * x2), rd, val[r]);                                                                  \
-      }                                                                                                        \
-    }                                                                                                          \
-  }
-  for (int k = 0; k < mmax; k += 2) {
-    TCH_PIVOT(k, 0)
-    if (k + 1 < mmax) TCH_PIVOT(k + 1, 1)
-  }
-#undef TCH_PIVOT
-  lds_barrier();   // rsd complete
-#pragma unroll
-  for (int r = 0; r < EPT; ++r)
-    if (eoff[r] >= 0) Bm[eoff[r]] = val[r] * rsd[khi[r]];
-  lds_barrier();
-}
-
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
 // One row of Kb doubles, global -> LDS, by LDS-DMA (16 bytes per lane, 1 KiB per wave-instruction, no registers): lane l

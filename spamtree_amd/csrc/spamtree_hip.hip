@@ -438,176 +438,88 @@ __global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
 // K/V live in LDS as KV[k][ldKV]; T^T is dumped into the same buffer for the epilogue.
 // ---------------------------------------------------------------------------------------------------------------
 
-// Cholesky + triangular inverse of an m x m (m <= 32) SPD matrix by ONE wave, entirely in registers: lane i owns
-// row i (identity-padded to 32), wave-uniform elements are broadcast with v_readlane (their indices are
-// compile-time constants after unrolling).  R: LDS, row-major m x m, lower triangle valid.  Ri (LDS, m x m) receives
-// chol(R)^{-1} with zeros above the diagonal.  *fail is set on a non-positive pivot (dpotrf's test).
+// 64-bit v_readlane (the lane index must be wave-uniform)
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, l);
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
-// shared core: in-register Cholesky (lane i owns row i) followed by the columns of L^{-1} (lane j owns column j).
-// dinv = 1 / L[lane][lane].  Divisions and square roots are replaced by one rsqrt per pivot.
-// MM = compile-time bound (m <= MM <= 32, rows/columns in [m, MM) are identity padding): no per-iteration branches.
-template <int MM>
-__device__ __forceinline__ void wave_chol_core(const double *SRC, int m, int lane, double (&a)[32], double (&x)[32], double &dinv, bool &bad) {
-  const int li = min(lane, m - 1);
-#pragma unroll
-  for (int j = 0; j < MM; ++j) {
-    const double v = SRC[li * m + min(j, m - 1)];
-    a[j] = (lane < m && j <= lane && j < m) ? v : ((j == lane) ? 1.0 : 0.0);
-  }
-#pragma unroll
-  for (int k = 0; k < MM; ++k) {
-    const double dkk = readlane_f64(a[k], k);
-    bad = bad || !(dkk > 0.0);
-    const double rs = rsqrt(dkk);
-    a[k] = (lane == k) ? dkk * rs : a[k] * rs;
-    dinv = (lane == k) ? rs : dinv;
-#pragma unroll
-    for (int j = k + 1; j < MM; ++j) a[j] -= a[k] * readlane_f64(a[k], j);
-  }
-#pragma unroll
-  for (int i = 0; i < MM; ++i) {
-    double sacc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) sacc -= readlane_f64(a[k], i) * x[k];
-    x[i] = sacc * readlane_f64(dinv, i);
-  }
-}
 
-template <int MM>
-__device__ void wave_chol_inverse_t(const double *R, int m, double *Ri, int *fail, int lane) {
-  double a[32], x[32], dinv = 1.0;
-  bool bad = false;
-  wave_chol_core<MM>(R, m, lane, a, x, dinv, bad);
-  if (bad && lane == 0) *fail = 1;
-  if (lane < m) {
-#pragma unroll
-    for (int i = 0; i < MM; ++i)
-      if (i < m) Ri[i * m + lane] = (i >= lane) ? x[i] : 0.0;
-  }
-}
-__device__ void wave_chol_inverse_32(const double *R, int m, double *Ri, int *fail, int lane) {
-  if (m <= 8) wave_chol_inverse_t<8>(R, m, Ri, fail, lane);
-  else if (m <= 16) wave_chol_inverse_t<16>(R, m, Ri, fail, lane);
-  else if (m <= 24) wave_chol_inverse_t<24>(R, m, Ri, fail, lane);
-  else if (m <= 28) wave_chol_inverse_t<28>(R, m, Ri, fail, lane);
-  else wave_chol_inverse_t<32>(R, m, Ri, fail, lane);
-}
-
-// Cholesky of S (m x m, m <= 32, LDS row-major, lower triangle valid) by one wave in registers, then
-// w = L^{-T} (L^{-1} b + z): the block-Gibbs draw of spamtree_model.cpp:1054, 1086.  The forward solve is column
-// oriented (broadcast of the solved entry); the transposed solve uses the columns of L^{-1}, so no cross-lane
-// reduction is needed: w_j = sum_i Li[i][j] u_i.
-template <int MM>
-__device__ void wave_chol_solve_t(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
-  double a[32], x[32], dinv = 1.0;
-  bool bad = false;
-  wave_chol_core<MM>(S, m, lane, a, x, dinv, bad);
-  if (bad && lane == 0) *fail = 1;
-  double u = (lane < m) ? b[lane] : 0.0;
-#pragma unroll
-  for (int k = 0; k < MM; ++k) {
-    const double uk = readlane_f64(u, k) * readlane_f64(dinv, k);
-    u = (lane == k) ? uk : ((lane > k) ? u - a[k] * uk : u);
-  }
-  u += (lane < m) ? z[lane] : 0.0;
-  double wj = 0.0;
-#pragma unroll
-  for (int i = 0; i < MM; ++i) wj += x[i] * readlane_f64(u, i);   // x[i] = Li[i][lane], zero for i < lane
-  if (lane < m) wout[lane] = wj;
-}
-__device__ void wave_chol_solve_32(const double *S, int m, const double *b, const double *z, double *wout, int *fail, int lane) {
-  if (m <= 8) wave_chol_solve_t<8>(S, m, b, z, wout, fail, lane);
-  else if (m <= 16) wave_chol_solve_t<16>(S, m, b, z, wout, fail, lane);
-  else if (m <= 24) wave_chol_solve_t<24>(S, m, b, z, wout, fail, lane);
-  else if (m <= 28) wave_chol_solve_t<28>(S, m, b, z, wout, fail, lane);
-  else wave_chol_solve_t<32>(S, m, b, z, wout, fail, lane);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Workgroup-wide (NT = 256 threads) right-looking Cholesky of an m x m (m <= 32) SPD matrix with the forward
-// elimination of the identity (-> L^{-1}) and / or of a right-hand side (-> L^{-1} u) carried along.
-// Every thread keeps up to three matrix elements in REGISTERS for the whole factorisation (lower triangle of A, lower
-// triangle of B = I, the vector u, concatenated and dealt round-robin); per pivot only the pivot column of A, the
-// pivot row of B and the pivot entry of u are published through a double-buffered LDS vector: one barrier per pivot.
-//   A  : LDS, row stride CH_LD, lower triangle valid on entry; receives L on exit
-//   Bm : LDS, row stride CH_LD, receives L^{-1} (lower; the caller zeroes / ignores the upper part); may be null
-//   u  : LDS vector, receives L^{-1} u; may be null
-//   pub: LDS scratch, 2 x 3 x 36 doubles;  rsd: 1 / L[k][k]
-// ---------------------------------------------------------------------------------------------------------------
 #define CH_LD 33
-#define CH_EPT 5
-__device__ void block_chol_eliminate(double *A, double *Bm, double *u, int m, double *pub, double *rsd, int *fail) {
-  const int tid = threadIdx.x;
-  const int nA = m * (m + 1) / 2, nB = Bm ? nA : 0, nU = u ? m : 0, nE = nA + nB + nU;
-  __syncthreads();   // A / u were just written by other threads
-  // per element: rank-1 updates while klo <= k < khi, scaling (and publication) at k == ksc
-  //   A[i][j]: klo 0, khi j, ksc j (the diagonal entry equals the pivot, so d*rs = val*rs)   published at pa[i]
-  //   B[i][j]: klo j, khi i, ksc i                                                          published at pa[36 + j]
-  //   u[i]   : klo 0, khi i, ksc i                                                          published at pa[72]
-  const int ept = (nE + NT - 1) / NT;   // elements per thread: 3 for m <= 26, up to 5 for m = 32 (uniform)
-  int ty[CH_EPT], ei[CH_EPT], ej[CH_EPT], o1[CH_EPT], o2[CH_EPT], klo[CH_EPT], khi[CH_EPT], ksc[CH_EPT], opub[CH_EPT];
-  double val[CH_EPT];
-#pragma unroll
-  for (int r = 0; r < CH_EPT; ++r) {
-    const int e = tid + NT * r;
-    ty[r] = 3; ei[r] = 0; ej[r] = 0; o1[r] = 0; o2[r] = 0; klo[r] = 0; khi[r] = 0; ksc[r] = -1; opub[r] = 0; val[r] = 0.0;
-    if (e < nE) {
-      int t = e < nA ? 0 : (e < nA + nB ? 1 : 2);
-      int f = e - (t == 0 ? 0 : (t == 1 ? nA : nA + nB));
-      int i, j;
-      if (t == 2) { i = f; j = 0; }
-      else {
-        i = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
-        while (i * (i + 1) / 2 > f) --i;
-        while ((i + 1) * (i + 2) / 2 <= f) ++i;
-        j = f - i * (i + 1) / 2;
-      }
-      ty[r] = t; ei[r] = i; ej[r] = j;
-      o1[r] = i;
-      o2[r] = t == 0 ? j : (t == 1 ? 36 + j : 72);   // second factor: column entry / row-k entry of B / u_k
-      klo[r] = t == 1 ? j : 0;
-      khi[r] = t == 0 ? j : i;
-      ksc[r] = t == 0 ? j : i;
-      opub[r] = t == 0 ? i : (t == 1 ? 36 + j : 72);
-      val[r] = t == 0 ? A[i * CH_LD + j] : (t == 1 ? (i == j ? 1.0 : 0.0) : u[i]);
-    }
-  }
-  for (int k = 0; k < m; ++k) {
-    double *pa = pub + (k & 1) * 108;          // [0,36): column k of A   [36,72): row k of B   [72]: u_k   (unscaled)
-#pragma unroll
-    for (int r = 0; r < CH_EPT; ++r)
-      if (r < ept && k == ksc[r]) pa[opub[r]] = val[r];
-    __syncthreads();
-    const double d = pa[k];
-    double x1[CH_EPT], x2[CH_EPT];
-#pragma unroll
-    for (int r = 0; r < CH_EPT; ++r) if (r < ept) { x1[r] = pa[o1[r]]; x2[r] = pa[o2[r]]; }
-    if (!(d > 0.0) && tid == 0) *fail = 1;
-    const double rs = rsqrt(d);
-    if (tid == 0) rsd[k] = rs;
-#pragma unroll
-    for (int r = 0; r < CH_EPT; ++r) if (r < ept) {
-      const double vu = val[r] - (x1[r] * rs) * (x2[r] * rs);
-      const double vs = val[r] * rs;
-      val[r] = (k >= klo[r] && k < khi[r]) ? vu : ((k == ksc[r]) ? vs : val[r]);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < CH_EPT; ++r) {
-    if (ty[r] == 0) A[ei[r] * CH_LD + ej[r]] = val[r];
-    if (ty[r] == 1) Bm[ei[r] * CH_LD + ej[r]] = val[r];
-    if (ty[r] == 2) u[ei[r]] = val[r];
-  }
-  __syncthreads();
-}
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// Team elimination [A | I] -> [. | L^{-1}] of an m x m SPD matrix (m <= 32): the workgroup is split into teams of TEAM
+// threads (128, or the whole workgroup), one matrix each; all teams run the same pivot loop (mmax = largest m, uniform) and share its barrier.
+// Every thread keeps EPT elements of the lower triangles of A and of B = I in registers (m (m + 1) <= TEAM * EPT).
+// Per pivot k the team publishes, UNSCALED, column k of A strictly below the diagonal, the pivot d_k itself, and row k
+// of B; everything outside those ranges reads as zero, so the update is the same two instructions for every element
+// at every pivot -- val -= (x1 x2) / d_k with x1 = A[i][k], x2 = A[j][k] or B[k][j] -- with no range tests; rows are
+// scaled by 1 / sqrt(d_i) once at the end.
+//   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).
+//   pub: 224 doubles per team: 2 x 96 published cells ([0,36) column, [36,72) row, [80] pivot, [95] always zero), rsd[32]
+typedef __attribute__((address_space(3))) double q_lds_double;
+template <int EPT, int TEAM = 128>
+__device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
+  const int nA = m * (m + 1) / 2, nE = 2 * nA;
+  double *rsd = pub + 192;
+  for (int i = ttid; i < 192; i += TEAM) pub[i] = 0.0;
+  lds_barrier();   // Am was written by other threads; pub is zero
+  // per element: 32-bit LDS addresses of its two factors and of its publication cell in buffer 0 (buffer 1 = +96
+  // doubles, an immediate offset in the unrolled pivot pair below), the pivot at which it is published, its output slot
+  q_lds_double *p1[EPT], *p2[EPT], *pp[EPT];
+  int khi[EPT], eoff[EPT];
+  double val[EPT];
+  q_lds_double *pub3 = (q_lds_double *)pub;
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int e = ttid + TEAM * r;
+    p1[r] = pub3 + 95; p2[r] = pub3 + 95; pp[r] = pub3 + 94; khi[r] = -1; eoff[r] = -1; val[r] = 0.0;
+    if (e < nE) {
+      const int t = e < nA ? 0 : 1;
+      const int f = e - t * nA;
+      int i = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > f) --i;
+      while ((i + 1) * (i + 2) / 2 <= f) ++i;
+      const int j = f - i * (i + 1) / 2;
+      p1[r] = pub3 + i;
+      p2[r] = pub3 + (t == 0 ? j : 36 + j);
+      pp[r] = pub3 + (t == 0 ? (i == j ? 80 : i) : 36 + j);
+      khi[r] = t == 0 ? j : i;
+      eoff[r] = t == 1 ? i * CH_LD + j : -1;
+      val[r] = t == 0 ? Am[i * CH_LD + j] : (i == j ? 1.0 : 0.0);
+    }
+  }
+#define TCH_PIVOT(k_, PAR)                                                                                     \
+  {                                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < EPT; ++r) if ((k_) == khi[r]) pp[r][(PAR) * 96] = val[r];            \
+    if (ttid == 0) { pub3[(PAR) * 96 + (k_)] = 0.0; if ((k_) > 0) pub3[(PAR) * 96 + (k_) - 1] = 0.0; }          \
+    lds_barrier();                                                                                             \
+    if ((k_) < m) {                                                                                            \
+      const double d = pub3[(PAR) * 96 + 80];                                                                  \
+      if (ttid == 0) { if (!(d > 0.0)) *fail = 1; rsd[(k_)] = rsqrt(d); }                                      \
+      double rd = __builtin_amdgcn_rcp(d);                                                                     \
+      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
+      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
+      _Pragma("unroll") for (int r = 0; r < EPT; ++r) {                                                        \
+        const double x1 = p1[r][(PAR) * 96], x2 = p2[r][(PAR) * 96];                                           \
+        val[r] = fma(-(x1 * x2), rd, val[r]);                                                                  \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+  for (int k = 0; k < mmax; k += 2) {
+    TCH_PIVOT(k, 0)
+    if (k + 1 < mmax) TCH_PIVOT(k + 1, 1)
+  }
+#undef TCH_PIVOT
+  lds_barrier();   // rsd complete
+#pragma unroll
+  for (int r = 0; r < EPT; ++r)
+    if (eoff[r] >= 0) Bm[eoff[r]] = val[r] * rsd[khi[r]];
+  lds_barrier();
+}
+
 
 #ifdef FM_STAMPS
 // diagnostic build only (never shipped): per-section shader-clock totals of k_factor_mfma, thread 0 of every workgroup
@@ -964,7 +876,11 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     for (int i = tid; i < s_am[t]; i += NT) wpa[s_ao[t] + i] = A.w[s_arow[t] + i];
   __syncthreads();
   // ---- Ri = chol(R)^{-1}: workgroup-wide elimination in LDS; then hv = T w_pa
-  if (refgrp) block_chol_eliminate(R, Ri, nullptr, M, chcol, chrs, &s_fail);
+  if (refgrp) {   // element slots per thread: m (m + 1) <= 256 * slots
+    if (M <= 22) team_chol_eliminate<2, NT>(R, Ri, M, M, chcol, &s_fail, tid);
+    else if (M <= 27) team_chol_eliminate<3, NT>(R, Ri, M, M, chcol, &s_fail, tid);
+    else team_chol_eliminate<5, NT>(R, Ri, M, M, chcol, &s_fail, tid);
+  }
   {
     const int w0 = wid, nw = 4;
     for (int j = w0; j < M; j += nw) {
