@@ -598,6 +598,8 @@ struct FastArgs {
   double *panels;
   double *logdet_c, *loglik_c;
   int *errflag;
+  const long long *gdesc;   // group descriptors of this launch's first group onwards
+  int gd_stride;
   int Pm4, ldKV, ldS, SRm, stage_dbl;
 };
 
@@ -632,27 +634,15 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
     const int per = A.ngrp >> 3;
     if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
   }
-  const Grp G = A.grps[gidx];
-  const int M = G.M, P = G.P;
-  const Blk B0 = A.blks[G.blk0];
-  const int J = B0.nanc;
-  if (tid < J) {
-    const int a = A.anc_idx[B0.anc_ptr + tid];
-    s_am[tid] = A.blks[a].m;
-    s_arow[tid] = A.blks[a].row0;
-    s_apan[tid] = A.blks[a].panel_off;
-  }
-  if (tid >= 64 && tid < 64 + G.nblk) {
-    const Blk Bb = A.blks[G.blk0 + tid - 64];
-    s_bpan[tid - 64] = Bb.panel_off; s_brow[tid - 64] = Bb.row0; s_bld[tid - 64] = Bb.ld;
-  }
-  if (tid == 0) s_fail = 0;
+  long long *s_gd = (long long *)stage;   // the group's descriptor lands in the (still unused) stage area: one round trip
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
   __syncthreads();
-  if (tid == 0) {
-    int o = 0;
-    for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-    s_ao[J] = o;
-  }
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, s_apan, nullptr, s_bpan, s_brow, s_bld, nullptr);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  const long long b0_panel_off = s_gd[8 + 4 * J];
+  const int b0_ld = (int)s_gd[8 + 4 * J + 2];
+  if (tid == 0) s_fail = 0;
   __syncthreads();
   // ---- prologue: coordinates (ancestors alias the stage area), K_{pa,u} into KV, pads zeroed
   {
@@ -895,8 +885,8 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
   STAMP(8);
   double wcore_part = 0.0, logdet_part = 0.0;
   if (refgrp) {
-    double *pu = A.panels + B0.panel_off;
-    const int ld = B0.ld;
+    double *pu = A.panels + b0_panel_off;
+    const int ld = b0_ld;
     // ---- N = -Ri * T : tiles (it, kt), A[i][j] = -Ri[i][j] (lower), B[j][k] = T^T[k][j]
     const int nkt = (P + 15) >> 4, nit = (M + 15) >> 4;
     for (int tile = wid; tile < nit * nkt; tile += NT / 64) {
@@ -3130,6 +3120,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
         F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p;
         F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
+        F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, h->stream, F, cp);
       } else if (L.bigmfma && h->factor_gen == 3) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
