@@ -79,7 +79,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ int s_smv[PMAX];
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, ttid = tid & 127;
-  const int wid = RFL(tid >> 6), u = wid >> 1, jt = wid & 1;
+  const int wid = RFL(tid >> 6), u = wid >> 1, jt = (wid & 1) ^ ((wid >> 2) & 1);   // waves w, w + 4 share a SIMD: one jt = 0 (it also has the off-diagonal Schur tile) and one jt = 1 each
   const int ldS = A.ldS;
   double *arena = lds;
   double *zrow = arena + (size_t)NU * 16 * ldS;   // a row of zeros
@@ -597,5 +597,5 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     if (ttid == 0 && Mu > 0 && s_fail[u]) atomicMin(A.errflag, s_level * 16 + 3);
   }
   STAMP(13);
-  STAMP_FLUSH;
+  STAMP_FLUSH_LEVEL(s_level);
 }

@@ -526,7 +526,11 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
 __device__ unsigned long long g_stamps[16];
 #define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_t0 = clock64(), st_t1 = 0;
 #define STAMP(slot) do { st_t1 = clock64(); st_acc[slot] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
-#define STAMP_FLUSH do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); } } while (0)
+__device__ int g_stamp_level = -1;   // >= 0: only workgroups of that tree level report (k_factor_quad)
+#define STAMP_FLUSH_IF(c_) do { if (threadIdx.x == 0 && (c_)) { for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); } } while (0)
+#define STAMP_FLUSH STAMP_FLUSH_IF(g_stamp_level < 0)
+#define STAMP_FLUSH_LEVEL(l_) STAMP_FLUSH_IF(g_stamp_level < 0 || g_stamp_level == (l_))
+extern "C" int st_debug_stamp_level(int level) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_level), &level, sizeof(int)); return 0; }
 extern "C" int st_debug_stamps(unsigned long long *out, int reset) {
   if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
@@ -536,6 +540,7 @@ extern "C" int st_debug_stamps(unsigned long long *out, int reset) {
 #define STAMP_DECL
 #define STAMP(slot) do {} while (0)
 #define STAMP_FLUSH do {} while (0)
+#define STAMP_FLUSH_LEVEL(l_) do {} while (0)
 #endif
 
 
