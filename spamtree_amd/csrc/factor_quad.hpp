@@ -499,6 +499,22 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     // LDS (slots overlay R and the elimination scratch), so the owner holds T for all of the unit's columns.
     double *xT = Ri + 32 * CH_LD;
     constexpr int NR = (NKT + 6) / 7;
+    // -Ri as A operands, the same for every chain tile: [row tile it][K-step r] (column tile 0), [r] (row tile 1, column tile 1)
+    double nri0[2][4], nri1[4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int i_a = it * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 4 * r + l4;
+        nri0[it][r] = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i_a = 16 + l15, j = 16 + 4 * r + l4;
+      nri1[r] = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
+    }
 #pragma unroll
     for (int rho = 0; rho < NR; ++rho) {
 #pragma unroll
@@ -527,21 +543,13 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
               if (it * 16 < Mu) {
-                const int i_a = it * 16 + l15;
                 d4 c = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  const int j = 4 * r + l4;
-                  const double a = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
-                  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T0[r], c, 0, 0, 0);
-                }
+                for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri0[it][r], T0[r], c, 0, 0, 0);
                 if (it == 1) {
 #pragma unroll
-                  for (int r = 0; r < 4; ++r) {
-                    const int j = 16 + 4 * r + l4;
-                    const double a = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
-                    if (16 + 4 * r < Mu) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T1[r], c, 0, 0, 0);
-                  }
+                  for (int r = 0; r < 4; ++r)
+                    if (16 + 4 * r < Mu) c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri1[r], T1[r], c, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
