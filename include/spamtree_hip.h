@@ -69,7 +69,10 @@ typedef struct st_options {
   int32_t force_generic;       /* 1 = use the global-scratch kernels even where the LDS kernels fit (testing)      */
   int32_t reserved;            /* bit 0: recompute the theta-only Gram part of the messages on every sweep, as the
                                   reference does (need_update is always true, spamtree_fit.cpp:184); default 0 caches it
-                                  per accepted theta -- identical values                               */
+                                  per accepted theta -- identical values
+                                  bit 1: limited_tree = TRUE (spamtree_fit.cpp:20, spamtree_model.cpp:901-903, 1275-1278):
+                                  parents(u) is the single parent of make_edges_limited (tree_dep.cpp:133-186), children(u)
+                                  the direct children, and Kxx_inv(u) = inv_sympd(K_uu); single GPU only                  */
 } st_options;
 
 /* ---- lifetime: SpamTreeMV::SpamTreeMV (spamtree_model.cpp:8-192) incl. init_indexing/init_finalize/init_model_data */

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
       s_anc[tid] = a;
       s_am[tid] = A.blks[a].m;
       s_arow[tid] = A.blks[a].row0;
-      s_apan[tid] = A.blks[a].panel_off;
+      s_apan[tid] = A.blks[a].chain_off;
     }
     if (tid == 0) s_fail = 0;
     __syncthreads();

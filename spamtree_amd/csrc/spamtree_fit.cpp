@@ -403,7 +403,6 @@ Rcpp::List spamtree_mv_mcmc(const arma::mat &y, const arma::mat &X, const arma::
                             const double &tausq, const arma::mat &mcmcsd, int mcmc_keep, int mcmc_burn, int mcmc_thin, int num_threads,
                             char use_alg, bool adapting, bool main_verbose, bool verbose, bool debug, bool printall, bool sample_beta,
                             bool sample_tausq, bool sample_theta, bool sample_w, bool sample_predicts) {
-  if (limited_tree) Rcpp::stop("limited_tree is not supported by the HIP build");
   auto csr = [](const arma::field<arma::uvec> &f, std::vector<int64_t> &ptr, std::vector<int64_t> &idx) {
     ptr.assign(f.n_elem + 1, 0);
     for (arma::uword i = 0; i < f.n_elem; ++i) ptr[i + 1] = ptr[i] + (int64_t)f(i).n_elem;
@@ -417,7 +416,7 @@ Rcpp::List spamtree_mv_mcmc(const arma::mat &y, const arma::mat &X, const arma::
   const int q = (int)Z.n_cols, p = (int)X.n_cols, k = (int)theta.n_elem;
   st_problem pb = {(int64_t)coords.n_rows, (int32_t)coords.n_cols, q, p, (int32_t)rr.size(), (int64_t)bn.size(), y.memptr(), X.memptr(),
                    coords.memptr(), mv.data(), rr.data(), bn.data(), bg.data(), ip.data(), ii.data(), pp.data(), pi.data(), cp.data(), ci.data()};
-  st_options opt = {0, 1, 0, 1, 0, 0};
+  st_options opt = {0, 1, 0, 1, 0, limited_tree ? 2 : 0};
   stm_flags fl = {adapting, sample_beta, sample_tausq, sample_theta, sample_w, sample_predicts};
   arma::cube beta_mcmc(p, mcmc_keep, q, arma::fill::zeros);
   arma::mat tausq_mcmc(q, mcmc_keep, arma::fill::zeros), theta_mcmc(k, mcmc_keep, arma::fill::zeros), paramsd(k, k, arma::fill::zeros);

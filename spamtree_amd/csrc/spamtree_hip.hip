@@ -55,7 +55,9 @@ struct Blk {
   long long acc_off;    // doubles, into the message arena
   int m, P, nanc, anc_ptr;
   int isref, nobs, dch_ptr, ndch;
-  int acc_len, level, ld, model_id;
+  int acc_len, level, ld, model_id;   // acc_len: on the device = offset of the children's records FOR this block inside their records
+  long long chain_off;  // panel the DESCENDANTS read as this block's rows of their chain factor: = panel_off, or (limited_tree)
+                        // the block's marginal inverse Cholesky chol(K_uu)^{-1}, m x m (k_marginal_invchol)
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -243,6 +245,47 @@ struct FactorArgs {
 #define MODE_FACTOR 0
 #define MODE_PREDICT 1
 
+// limited_tree (/root/reference/src/spamtree_model.cpp:901-903, 1275-1278: Kxx_inv(u) = inv_sympd(K_uu), every block has
+// ONE parent, /root/reference/src/tree_dep.cpp:133-186): the chain factor the children of u work with is the block's MARGINAL
+// inverse Cholesky chol(K_uu)^{-1} (m x m, row-major, Blk::chain_off), not its conditional panel.  One workgroup per block.
+struct MarginalArgs {
+  const Blk *blks;
+  const int *list;
+  int nlist;
+  const double *cx, *cy;
+  const int *mv;
+  double *panels;
+  int *errflag;
+  int maxM;
+};
+__global__ __launch_bounds__(NT) void k_marginal_invchol(MarginalArgs A, CovPar cp) {
+  extern __shared__ double lds[];   // K (m x m) | L^{-1} (m x m)
+  __shared__ int s_fail;
+  const int tid = threadIdx.x;
+  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
+    const Blk B = A.blks[A.list[li]];
+    const int m = B.m;
+    double *K = lds, *Li = lds + (size_t)A.maxM * A.maxM;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int idx = tid; idx < m * m; idx += NT) {
+      const int i = idx / m, j = idx - i * m;
+      const long long ri = B.row0 + i, rj = B.row0 + j;
+      K[idx] = (j <= i) ? cov_entry(cp, A.cx[ri], A.cy[ri], A.mv[ri], A.cx[rj], A.cy[rj], A.mv[rj]) : 0.0;
+    }
+    __syncthreads();
+    chol_lower_inplace(K, m, &s_fail);
+    tri_inverse_lower(K, Li, m);
+    double *out = A.panels + B.chain_off;
+    for (int idx = tid; idx < m * m; idx += NT) {
+      const int i = idx / m, j = idx - i * m;
+      out[idx] = (j <= i) ? Li[idx] : 0.0;
+    }
+    if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + 2);   // errtype 2 (:919), reported at the block's level
+    __syncthreads();
+  }
+}
+
 template <bool BIG, int MODE>
 __global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
   extern __shared__ double lds[];
@@ -281,7 +324,7 @@ __global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
       s_anc[tid] = a;
       s_am[tid] = A.blks[a].m;
       s_arow[tid] = A.blks[a].row0;
-      s_apan[tid] = A.blks[a].panel_off;
+      s_apan[tid] = A.blks[a].chain_off;
     }
     if (tid == 0) s_fail = 0;
     __syncthreads();
@@ -980,6 +1023,7 @@ struct SampleArgs {
   long long scratch_stride;
   int maxP, maxM, maxLd;
   int do_gram;
+  int no_fwd;   // limited_tree: a block's record goes to its single parent only, nothing is forwarded from its children
   double tausq_inv[QMAX];
 };
 
@@ -1151,7 +1195,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) a -= x[rr] * ((r0 + rr < m) ? avt[r0 + rr] : 0.0);
         }
-        for (int c = 0; c < B.ndch; ++c) {
+        for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
           const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
           a += A.acc[C.acc_off + s_aoff[t] + ma * ma + i];
         }
@@ -1179,7 +1223,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
           const int i = idx - ma * ma;
           for (int r = 0; r < m; ++r) acc -= N[(size_t)r * ld + oa + i] * av[r];
         }
-        for (int c = 0; c < B.ndch; ++c) {
+        for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
           const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
           acc += A.acc[C.acc_off + off + idx];
         }
@@ -1215,6 +1259,7 @@ struct SampleFastArgs {
   int gd_stride;
   int ldN, Mr4, Mrows, maxP, av_dbl;   // Mrows: staged panel rows (the level's largest group)   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
   int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
+  int no_fwd;    // limited_tree: nothing is forwarded from the children's records
   double tausq_inv[QMAX];
 };
 
@@ -1374,14 +1419,15 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
       double *out = rec + s_aoff[t];
       // children's records: all loads of a chunk of four children are issued together (fixed summation order)
       double chv[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int c0 = 0; c0 < s_nch; c0 += 4) {
+      const int nfw = A.no_fwd ? 0 : s_nch;
+      for (int c0 = 0; c0 < nfw; c0 += 4) {
         double ld4[4][4];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-            ld4[cc][r] = (c0 + cc < s_nch && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + s_aoff[t] + i * ma + j] : 0.0;
+            ld4[cc][r] = (c0 + cc < nfw && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, nfw - 1)] + s_aoff[t] + i * ma + j] : 0.0;
           }
         }
 #pragma unroll
@@ -1462,7 +1508,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
     if (i < ma) {
       double a = 0.0;
       double ch[4];   // the children's vectors: requested before the dot product, added after it in a fixed order
-      const int nch = s_nch;
+      const int nch = A.no_fwd ? 0 : s_nch;
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
       for (int r = 0; r < M; ++r) a -= Np[(size_t)r * ldN + oa + i] * av[t * 32 + r];
@@ -1657,7 +1703,7 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
     const int ma = s_am[t], i = k - s_ao[t];
     const double *avt = seg + t * 32;
     double ch[4];   // the children's vectors: requested first, added after the dot product in a fixed order
-    const int nch = s_nch;
+    const int nch = A.no_fwd ? 0 : s_nch;
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
     double a = 0.0;
@@ -2169,6 +2215,10 @@ struct st_handle_s {
   double *pin = nullptr;                      // 64 doubles of pinned host memory for the small device-to-host reads
   bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
   bool cache_gram = true;
+  bool limited = false;               // limited_tree: single parents, marginal chain factors (k_marginal_invchol)
+  std::vector<int> twin_list;         // limited_tree: device ids of the blocks that own a chain panel
+  DevBuf<int> d_twin;
+  int twin_maxM = 1;
   ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
   std::vector<LevelInfo> levels;
   LevelInfo pred_info;
@@ -2281,7 +2331,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
+  h->d_twin.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
@@ -2320,6 +2370,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   h->quirks = opt ? opt->reference_quirks : 1;
   h->force_generic = opt ? opt->force_generic : 0;
   h->cache_gram = !(opt && (opt->reserved & 1));
+  h->limited = opt && (opt->reserved & 2);
+  if (h->limited && h->world > 1) return fail_create(h, ST_ERR_UNSUPPORTED, "limited_tree with world > 1");
   const long long n = pb->n_all, nb = pb->n_blocks;
   h->n_all = n; h->n_blocks = nb; h->q = pb->q; h->p = pb->p; h->d = pb->d; h->n_groups = pb->n_groups;
   for (int j = 0; j < QMAX; ++j) h->tausq_inv[j] = 1.0;
@@ -2411,20 +2463,33 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       P += m_of[a];
     }
     B.P = P;
-    if (B.nanc > 0) {
+    if (h->limited) {
+      if (B.nanc > 1) return fail_create(h, ST_ERR_TOPOLOGY, "limited_tree: a block has more than one parent (make_edges_limited gives one)");
+    } else if (B.nanc > 0) {
       const long long last = pb->parents_idx[p1 - 1];
       const long long q0 = pb->parents_ptr[last], q1 = pb->parents_ptr[last + 1];
       bool ok = (q1 - q0) == (p1 - p0 - 1);
       for (long long k = 0; ok && k < q1 - q0; ++k) ok = pb->parents_idx[q0 + k] == pb->parents_idx[p0 + k];
-      if (!ok) return fail_create(h, ST_ERR_UNSUPPORTED, "parents(u) is not parents(last parent)+[last parent] (limited_tree is not supported)");
+      if (!ok) return fail_create(h, ST_ERR_UNSUPPORTED, "parents(u) is not parents(last parent)+[last parent]: for make_edges_limited's single-parent lists set the limited_tree bit of st_options");
     }
     const bool observed = B.nobs > 0;
     B.isref = (observed && B.level < pb->n_groups && pb->res_is_ref[B.level] == 1) ? 1 : 0;
     B.ld = B.P + (B.isref ? B.m : 1);
     B.panel_off = -1; B.acc_off = 0; B.acc_len = 0;
+    B.chain_off = -1;
     if (observed) {
       B.panel_off = panel_total;
       panel_total += (long long)B.m * B.ld;
+      B.chain_off = B.panel_off;
+      if (h->limited) {
+        B.chain_off = -1;
+        if (B.isref) {   // every observed reference block may be somebody's parent (observed or prediction children)
+          B.chain_off = panel_total;
+          panel_total += (long long)B.m * B.m;
+          h->twin_list.push_back(i);
+          h->twin_maxM = std::max(h->twin_maxM, B.m);
+        }
+      }
     }
   }
   // acc layout + direct children
@@ -2791,7 +2856,14 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   CCHK(h->d_cx.upload(cx)); CCHK(h->d_cy.upload(cy)); CCHK(h->d_y.upload(y)); CCHK(h->d_X.upload(X));
   CCHK(h->d_mv.upload(mv)); CCHK(h->d_obs.upload(obs)); CCHK(h->d_partner.upload(partner));
   CCHK(h->d_dev2model.upload(h->dev2model));
-  CCHK(h->d_blks.upload(h->blks));
+  {
+    // device copy: acc_len = where, inside a child's record, the part FOR this block starts (after the block's own
+    // ancestors in the full tree; at 0 when every block has a single parent)
+    std::vector<Blk> db = h->blks;
+    if (h->limited) for (Blk &B : db) B.acc_len = 0;
+    CCHK(h->d_blks.upload(db));
+    if (h->limited) { std::vector<int> t = h->twin_list; if (t.empty()) t.push_back(0); CCHK(h->d_twin.upload(t)); }
+  }
   { std::vector<int> a = h->anc_idx; if (a.empty()) a.push_back(0); CCHK(h->d_anc.upload(a)); }
   { std::vector<int> a = h->dch_idx; if (a.empty()) a.push_back(0); CCHK(h->d_dch.upload(a)); }
   CCHK(h->d_lvl.upload(h->lvl_list));
@@ -2814,12 +2886,12 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       long long *w = h->gdesc.data() + g * (size_t)stride;
       const int nch = std::min(B0.ndch, 64);
       w[0] = G.row0; w[1] = B0.acc_off; w[2] = pack(G.M, G.P); w[3] = pack(B0.nanc, G.nblk); w[4] = pack(B0.isref, B0.level);
-      w[5] = pack(nch, B0.acc_len); w[6] = pack(G.blk0, 0);
+      w[5] = pack(nch, h->limited ? 0 : B0.acc_len); w[6] = pack(G.blk0, 0);
       long long ao = 0, aoff = 0;
       for (int t = 0; t < B0.nanc; ++t) {
         const Blk &Ba = h->blks[h->anc_idx[B0.anc_ptr + t]];
         long long *a = w + 8 + 4 * t;
-        a[0] = pack(Ba.m, ao); a[1] = Ba.row0; a[2] = Ba.panel_off; a[3] = aoff;
+        a[0] = pack(Ba.m, ao); a[1] = Ba.row0; a[2] = Ba.chain_off; a[3] = aoff;
         ao += Ba.m; aoff += (long long)Ba.m * Ba.m + Ba.m;
       }
       w[7] = aoff;
@@ -2893,6 +2965,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<4, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_marginal_invchol, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
     // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
     // chains <= 200 rows, LDS fits) and k_factor_mfma elsewhere; 1 = k_factor_mfma everywhere
@@ -3092,6 +3165,13 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
   int n_launch = 0;
   for (int g = 0; g < h->n_actual_groups; ++g) n_launch += ((h->levels[g].fast ? h->levels[g].gown_n : h->levels[g].own_n) != 0);
   ProfScope phase(h, 0, -2, n_launch);   // profile mode 2: the phase's launches between ONE pair of events (mean launch = total / launches)
+  if (h->limited && !h->twin_list.empty()) {
+    MarginalArgs M;
+    M.blks = h->d_blks.p; M.list = h->d_twin.p; M.nlist = (int)h->twin_list.size(); M.cx = h->d_cx.p; M.cy = h->d_cy.p; M.mv = h->d_mv.p;
+    M.panels = h->d_panels[phys].p; M.errflag = h->d_err.p; M.maxM = h->twin_maxM;
+    const size_t lds = (size_t)2 * h->twin_maxM * h->twin_maxM * sizeof(double);
+    hipLaunchKernelGGL(k_marginal_invchol, dim3(std::min(M.nlist, 8 * h->sm_count)), dim3(NT), lds, h->stream, M, cp);
+  }
   for (int g = 0; g < h->n_actual_groups; ++g) {
     const LevelInfo &L = h->levels[g];
     if ((L.fast ? L.gown_n : L.own_n) == 0) continue;
@@ -3300,12 +3380,13 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
     A.obs = h->d_obs.p; A.acc = h->d_acc.p; A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxLd = L.maxLd;
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
     A.do_gram = (h->gram_valid && h->cache_gram) ? 0 : 1;
+    A.no_fwd = h->limited ? 1 : 0;
     {
       ProfScope ps(h, 1, h->n_actual_groups + g);   // per-level slots of phase B follow those of phase A
       if (L.fast) {
         SampleFastArgs F;
         std::memset(&F, 0, sizeof(F));
-        F.do_gram = A.do_gram;
+        F.do_gram = A.do_gram; F.no_fwd = A.no_fwd;
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.dch_idx = h->d_dch.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.panels = h->d_panels[phys].p; F.w = h->d_w.p; F.y = h->d_y.p; F.xb = h->d_xb.p; F.z = h->d_z.p; F.mv = h->d_mv.p;
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.Mrows = L.Mrows; F.maxP = L.maxP; F.av_dbl = L.av_dbl;

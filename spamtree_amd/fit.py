@@ -45,8 +45,6 @@ class Chain:
                  block_names, block_groups, indexing, set_unif_bounds, theta, beta, tausq, mcmcsd, seed=2021,
                  adapting=True, sample_beta=True, sample_tausq=True, sample_theta=True, sample_w=True, device=0,
                  reference_quirks=True, rank=0, world=1, unique_id=None):
-        if limited_tree:
-            raise SpamTreeError("limited_tree=TRUE is not supported by the HIP build")
         self.lib = _lib.load()
         pb, self._keep, self.n, self.p, self.q = _problem(y, X, coords, mv_id, res_is_ref, parents, children,
                                                           block_names, block_groups, indexing)
@@ -54,7 +52,7 @@ class Chain:
         self.k = theta.size
         bounds = np.asfortranarray(np.asarray(set_unif_bounds, dtype=np.float64))
         sd = np.asfortranarray(np.asarray(mcmcsd, dtype=np.float64))
-        opt = _lib.StOptions(int(device), int(bool(reference_quirks)), int(rank), int(world), 0, 0)
+        opt = _lib.StOptions(int(device), int(bool(reference_quirks)), int(rank), int(world), 0, 2 if limited_tree else 0)
         fl = _lib.StmFlags(int(adapting), int(sample_beta), int(sample_tausq), int(sample_theta), int(sample_w), 1)
         c = C.c_void_p()
         self.c = None
@@ -146,15 +144,13 @@ def spamtree_mv_mcmc(y, X, Z, coords, mv_id, blocking, gix_block, res_is_ref, pa
                      sample_theta=True, sample_w=True, sample_predicts=True, seed=2021, device=0, reference_quirks=True):
     """spamtree_fit.cpp:5-430 through the C++ driver.  `num_threads`, `use_alg`, the verbosity flags and `start_w` are
     accepted and ignored exactly where the reference ignores them (start_w, :95) or where they do not apply to a GPU."""
-    if limited_tree:
-        raise SpamTreeError("limited_tree=TRUE is not supported by the HIP build")
     lib = _lib.load()
     pb, keep, n, p, q = _problem(y, X, coords, mv_id, res_is_ref, parents, children, layer_names, layer_gibbs_group, indexing)
     theta = _f64(theta)
     k = theta.size
     bounds = np.asfortranarray(np.asarray(set_unif_bounds_in, dtype=np.float64))
     sd = np.asfortranarray(np.asarray(mcmcsd, dtype=np.float64))
-    opt = _lib.StOptions(int(device), int(bool(reference_quirks)), 0, 1, 0, 0)
+    opt = _lib.StOptions(int(device), int(bool(reference_quirks)), 0, 1, 0, 2 if limited_tree else 0)
     fl = _lib.StmFlags(int(adapting), int(sample_beta), int(sample_tausq), int(sample_theta), int(sample_w), int(sample_predicts))
     w_all = np.zeros((n, mcmc_keep), order="F"); yh_all = np.zeros((n, mcmc_keep), order="F")
     beta_mcmc = np.zeros((p, mcmc_keep, q), order="F"); tausq_mcmc = np.zeros((q, mcmc_keep), order="F")

@@ -49,8 +49,6 @@ class SpamTreeMV:
     def __init__(self, y, X, Z, coords, mv_id, blocking, gix_block, res_is_ref, parents, children, limited_tree,
                  block_names, block_groups, indexing, w, beta, theta, tausq_inv,
                  device=0, reference_quirks=True, force_generic=False, rank=0, world=1, cache_gram=True):
-        if limited_tree:
-            raise SpamTreeError("limited_tree=TRUE is not supported by the HIP build (SURVEY.md section 8f-4)")
         self.lib = _lib.load()
         y = _f64(np.asarray(y).reshape(-1))
         X = np.asfortranarray(np.asarray(X, dtype=np.float64))
@@ -67,7 +65,8 @@ class SpamTreeMV:
         pb = _lib.StProblem(self.n_all, self.dd, self.q, self.p, int(keep[4].size), int(keep[5].size),
                             _dp(y), _dp(X), _dp(coords), _ip(mv_id), _ip(keep[4]), _ip(keep[5]), _ip(keep[6]),
                             _ip(keep[7]), _ip(keep[8]), _ip(keep[9]), _ip(keep[10]), _ip(keep[11]), _ip(keep[12]))
-        opt = _lib.StOptions(int(device), int(bool(reference_quirks)), int(rank), int(world), int(bool(force_generic)), 0 if cache_gram else 1)
+        opt = _lib.StOptions(int(device), int(bool(reference_quirks)), int(rank), int(world), int(bool(force_generic)),
+                              (0 if cache_gram else 1) | (2 if limited_tree else 0))
         self.rank, self.world = int(rank), int(world)
         h = C.c_void_p()
         rc = self.lib.st_create(C.byref(pb), C.byref(opt), C.byref(h))

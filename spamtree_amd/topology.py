@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 __all__ = [
-    "kthresholds", "part_axis_parallel", "make_tree", "make_edges", "prepare", "Topology", "TreeResult",
+    "kthresholds", "part_axis_parallel", "make_tree", "make_edges", "make_edges_limited", "prepare", "Topology", "TreeResult",
     "grid_coords",
 ]
 
@@ -289,6 +289,48 @@ def make_edges(parchimat: np.ndarray, non_empty_blocks: np.ndarray, res_is_ref: 
     return (par_ptr, par_idx), (chi_ptr, chi_idx)
 
 
+def make_edges_limited(parchimat: np.ndarray, non_empty_blocks: np.ndarray, res_is_ref: np.ndarray):
+    """``limited_tree = TRUE``: parents(u) = the block of u's rows on the LAST reference level above u (one block),
+    children(u) = the non-empty blocks of u's rows on the NEXT level only.
+
+    Same contract as /root/reference/src/tree_dep.cpp:133-186 (selected at /root/reference/R/spamtree_fit.R:310-311):
+    0-based ids, ascending; ``parchimat`` holds 1-based block ids with 0 for NA; ``non_empty_blocks`` is 1-based.
+    """
+    parchimat = np.asarray(parchimat, dtype=np.int64)
+    L = parchimat.shape[1]
+    n_blocks = int(parchimat.max())
+    res_is_ref = np.asarray(res_is_ref, dtype=np.int64)
+    non_empty = np.zeros(n_blocks + 1, dtype=bool)
+    non_empty[np.asarray(non_empty_blocks, dtype=np.int64)] = True
+    ref_cols = np.nonzero(res_is_ref == 1)[0]
+    par_pairs, chi_pairs = [], []
+    for lev in range(L):
+        col = parchimat[:, lev]
+        ok = col > 0
+        if lev > 0:
+            cols = ref_cols[ref_cols < lev] if ref_cols.size > 0 else np.arange(lev)
+            c = int(cols[-1])
+            sel = ok & (parchimat[:, c] > 0)
+            par_pairs.append(np.unique(np.column_stack([col[sel], parchimat[sel, c]]), axis=0))
+        if res_is_ref[lev] == 1 and lev < L - 1:
+            sel = ok & (parchimat[:, lev + 1] > 0)
+            pr = np.unique(np.column_stack([col[sel], parchimat[sel, lev + 1]]), axis=0)
+            chi_pairs.append(pr[non_empty[pr[:, 1]]])
+
+    def _to_lists(pairs):
+        ptr = np.zeros(n_blocks + 1, dtype=np.int64)
+        if not pairs:
+            return ptr, np.zeros(0, dtype=np.int64)
+        allp = np.unique(np.concatenate(pairs, axis=0), axis=0)
+        cnt = np.bincount(allp[:, 0] - 1, minlength=n_blocks)
+        ptr[1:] = np.cumsum(cnt)
+        return ptr, allp[:, 1] - 1
+
+    par_ptr, par_idx = _to_lists(par_pairs)
+    chi_ptr, chi_idx = _to_lists(chi_pairs)
+    return (par_ptr, par_idx), (chi_ptr, chi_idx)
+
+
 @dataclass
 class Topology:
     """Everything `spamtree_mv_mcmc` receives from R (spamtree_fit.R:327-362), in the sorted row order.
@@ -330,7 +372,8 @@ class Topology:
 def prepare(y: np.ndarray, coords: np.ndarray, mv_id: Optional[np.ndarray] = None,
             cell_size: int = 25, K: Optional[Sequence[int]] = None, start_level: int = 0,
             tree_depth: float = np.inf, last_not_reference: bool = True,
-            cherrypick_same_margin: bool = True, cherrypick_group_locations: bool = True) -> Topology:
+            cherrypick_same_margin: bool = True, cherrypick_group_locations: bool = True,
+            limited_tree: bool = False) -> Topology:
     """Row sorting, tree, edges and indexing exactly as `spamtree()` hands them to C++ (spamtree_fit.R:196-324).
 
     ``y`` may contain NaN (= NA).  Returns arrays in the *sorted* row order (by coordinates, then original id).
@@ -377,7 +420,8 @@ def prepare(y: np.ndarray, coords: np.ndarray, mv_id: Optional[np.ndarray] = Non
 
     obs_cnt = np.bincount(blocking - 1, weights=np.isfinite(ys).astype(np.float64), minlength=n_blocks)
     non_empty_blocks = np.nonzero(obs_cnt > 0)[0] + 1
-    (pp, pi), (cp, ci) = make_edges(tree.parchi_map, non_empty_blocks, tree.res_is_ref)
+    edges = make_edges_limited if limited_tree else make_edges          # spamtree_fit.R:310-314
+    (pp, pi), (cp, ci) = edges(tree.parchi_map, non_empty_blocks, tree.res_is_ref)
 
     block_groups = np.zeros(n_blocks, dtype=np.int64)
     block_groups[blocking - 1] = res_row

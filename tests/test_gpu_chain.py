@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def args_of(pb, k):
     return (pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"], pb["res_is_ref"],
-            pb["parents"], pb["children"], False, pb["block_names"], pb["block_groups"], pb["indexing"], pb["bounds"],
+            pb["parents"], pb["children"], pb.get("limited_tree", False), pb["block_names"], pb["block_groups"], pb["indexing"], pb["bounds"],
             np.zeros((pb["n"], 1)), pb["theta"], np.zeros(pb["p"]), 0.1, 0.01 * np.eye(k))
 
 
@@ -19,7 +19,8 @@ def relerr(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(np.asarray(b)).max()))
 
 
-@pytest.mark.parametrize("case", [dict(side=25, q=1, seed=11, missing=0.1), dict(side=12, q=2, seed=12)])
+@pytest.mark.parametrize("case", [dict(side=25, q=1, seed=11, missing=0.1), dict(side=12, q=2, seed=12),
+                                  dict(side=25, q=1, seed=13, missing=0.1, limited_tree=True)])
 def test_cpp_and_python_drivers_match_oracle_chain(case):
     from oracle import spamtree_oracle as so
     from spamtree_amd import fit, mcmc
@@ -43,7 +44,7 @@ def test_cpp_chain_steps_and_reports_state():
     from spamtree_amd import fit
     pb = make_problem(side=25, q=1, seed=3)
     ch = fit.Chain(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"], pb["res_is_ref"],
-                   pb["parents"], pb["children"], False, pb["block_names"], pb["block_groups"], pb["indexing"],
+                   pb["parents"], pb["children"], pb.get("limited_tree", False), pb["block_names"], pb["block_groups"], pb["indexing"],
                    pb["bounds"], pb["theta"], np.zeros(pb["p"]), 0.1, 0.01 * np.eye(4), seed=5)
     ch.step(20)
     st = ch.state()

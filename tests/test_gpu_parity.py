@@ -20,7 +20,7 @@ def hip_model(pb, theta=None, beta=None, tausq=0.1, w=None, **kw):
     beta = np.zeros(pb["p"]) if beta is None else beta
     w = np.zeros(pb["n"]) if w is None else w
     return SpamTreeMV(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"],
-                      pb["res_is_ref"], pb["parents"], pb["children"], False, pb["block_names"],
+                      pb["res_is_ref"], pb["parents"], pb["children"], pb.get("limited_tree", False), pb["block_names"],
                       pb["block_groups"], pb["indexing"], w, beta, theta, 1.0 / tausq, **kw)
 
 

@@ -70,6 +70,7 @@ def make_problem(side=25, q=1, seed=0, missing=0.0, coords=None, mv_id=None, p=3
     if missing > 0:
         y = y.copy()
         y[rng.uniform(size=n) < missing] = np.nan
+    limited_tree = bool(tree_kw.get("limited_tree", False))
     topo = prepare(y, coords, mv_id, **tree_kw)
     s = topo.sort_ix
     Z = np.zeros((n, q))
@@ -81,7 +82,7 @@ def make_problem(side=25, q=1, seed=0, missing=0.0, coords=None, mv_id=None, p=3
         children=csr_to_lists(topo.children_ptr, topo.children_idx),
         block_names=topo.block_names, block_groups=topo.block_groups,
         indexing=csr_to_lists(topo.indexing_ptr, topo.indexing_idx),
-        q=q, p=p, n=n, beta_true=beta, bounds=default_bounds(q), theta=nice_theta(q))
+        q=q, p=p, n=n, beta_true=beta, bounds=default_bounds(q), theta=nice_theta(q), limited_tree=limited_tree)
 
 
 def oracle_model(pb, theta=None, beta=None, tausq=0.1, w=None, **kw):
@@ -90,5 +91,5 @@ def oracle_model(pb, theta=None, beta=None, tausq=0.1, w=None, **kw):
     beta = np.zeros(pb["p"]) if beta is None else beta
     w = np.zeros(pb["n"]) if w is None else w
     return SpamTreeMV(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"],
-                      pb["res_is_ref"], pb["parents"], pb["children"], False, pb["block_names"],
+                      pb["res_is_ref"], pb["parents"], pb["children"], pb.get("limited_tree", False), pb["block_names"],
                       pb["block_groups"], pb["indexing"], w, beta, theta, 1.0 / tausq, **kw)
