@@ -148,7 +148,7 @@ def main():
     chain.step(n_extra)
     fence()
     prof_all = model.profile_get()
-    lvl_ms, lvl_bytes = model.profile_levels()   # per-level phase-A times come from this pass too
+    lvl_ms, lvl_bytes, smp_ms, smp_bytes = model.profile_levels_all()   # per-level phase-A / phase-B times come from this pass too
     model.profile(0)
     n_levels = max(1, len(lvl_ms))
     avg_launch_ms = fac_ms / max(1, fac_n)
@@ -189,6 +189,9 @@ def main():
                      "by_level_ms": [round(float(x), 4) for x in lvl_ms],
                      "by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
                                        for b, m in zip(lvl_bytes, lvl_ms)],
+                     "sample_by_level_ms": [round(float(x), 4) for x in smp_ms],
+                     "sample_by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
+                                              for b, m in zip(smp_bytes, smp_ms)],
                      "phase_ms_per_iter": {kk: round((prof[kk][0] / args.steps) if kk == "factor" else (v[0] / n_extra), 4)
                                            for kk, v in prof_all.items()},
                      "phase_ms_note": "factor (and avg_launch_ms, achieved): one HIP-event pair around each phase A of the timed "

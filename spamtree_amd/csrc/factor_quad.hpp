@@ -492,8 +492,12 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   if constexpr (ISREF) {
     // element slots per thread: m (m + 1) <= 128 * slots
     // element slots per thread: m (m + 1) <= 128 * slots.  (One wave per unit without barriers was tried: slower.)
-    if (Mmax <= 27) team_chol_eliminate<6>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
-    else team_chol_eliminate<9>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
+    if (Mmax <= 27) {
+      // one wave per unit, registers only (the jt = 0 waves sit on four different SIMDs); the partner waits at the barrier
+      lds_barrier();   // R complete (both waves of the unit wrote parts of it)
+      if (jt == 0) wave_chol_eliminate<27>(R, Ri, Mu, &s_fail[u], lane);
+      lds_barrier();
+    } else team_chol_eliminate<9>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
     STAMP(7);
     // ---- N = -Ri T.  Chain tiles alternate between the unit's two waves; the non-owner hands its T tile over through
     // LDS (slots overlay R and the elimination scratch), so the owner holds T for all of the unit's columns.

@@ -564,6 +564,48 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
 }
 
 
+// The same elimination by ONE wave, without LDS traffic or barriers: lane i keeps row i of A (lower triangle) and of
+// B = I in registers; per pivot the pivot, column k of A (lane j's a[k]) and row k of B (lane k's b[j]) travel through
+// v_readlane (wave-uniform SGPR operands of the updates).  Fully unrolled (static register indices): MM pivots of MM
+// broadcasts + MM fused multiply-adds, about 400 cycles per pivot on an otherwise idle SIMD -- the team version's pivot
+// costs a workgroup barrier round trip (about 1.4k cycles with eight waves).  m <= MM <= 32; rows >= m behave as identity.
+//   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).  All 64 lanes must call.
+template <int MM>
+__device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm, int m, int *fail, int lane) {
+  double a[MM], b[MM];
+  const bool row = lane < m;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    a[j] = (row && j <= lane) ? Am[min(lane, 31) * CH_LD + j] : (j == lane ? 1.0 : 0.0);
+    b[j] = j == lane ? 1.0 : 0.0;
+  }
+  double dd = 1.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < MM; ++k) {
+    if (k < m) {   // wave-uniform
+      const double d = readlane_f64(a[k], k);
+      bad = bad || !(d > 0.0);
+      dd = lane == k ? d : dd;
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      const double f = lane > k ? -a[k] * rd : 0.0;
+#pragma unroll
+      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
+#pragma unroll
+      for (int j = 0; j <= k; ++j) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
+    }
+  }
+  if (bad && lane == 0) *fail = 1;
+  const double rs = rsqrt(dd);
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < MM; ++j)
+      if (j <= lane) Bm[lane * CH_LD + j] = b[j] * rs;
+  }
+}
+
 #ifdef FM_STAMPS
 // diagnostic build only (never shipped): per-section shader-clock totals of k_factor_mfma, thread 0 of every workgroup
 __device__ unsigned long long g_stamps[16];

@@ -116,6 +116,13 @@ class Chain:
         self.lib.st_profile_levels(self.h, C.byref(nl), _dp(ms), _dp(by), 64)
         return ms[: nl.value].copy(), by[: nl.value].copy()
 
+    def profile_levels_all(self):
+        """(phase A ms, phase A algorithmic bytes, phase B ms, phase B + message bytes) per level since the last call."""
+        nl = C.c_int32(); ms = np.zeros(128); by = np.zeros(128)
+        self.lib.st_profile_levels(self.h, C.byref(nl), _dp(ms), _dp(by), 128)
+        k = nl.value
+        return ms[:k].copy(), by[:k].copy(), ms[k: 2 * k].copy(), by[k: 2 * k].copy()
+
     def synchronize(self):
         self.lib.st_synchronize(self.h)
 
