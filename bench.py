@@ -17,8 +17,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "c_quad_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py
+PMC_SUMMARY = "d_wavechol_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6    # FP64 matrix = FP64 vector peak; both run on ONE pipe per SIMD (profiles/r01/micro_f64_pipes.log)
 
 
 def reference_cost(wl):
@@ -186,6 +187,13 @@ def main():
                      "traffic": traffic, "avg_launch_ms": avg_launch_ms, "launches": fac_n,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "whole_iteration_GBps": alg["total"] / (dt / args.steps) / 1e9,
+                     # secondary view: the kernel's HBM traffic is ~5x below its algorithmic bytes (chain panels come from
+                     # L2 / Infinity Cache), what saturates is the SIMDs' FP64 pipe -- useful flops of phase A over its time
+                     "fp64_pipe": {"achieved": alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_levels * 1e-3) / 1e12
+                                   if fac_ms > 0 else 0.0, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": (alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_levels * 1e-3) / 1e12
+                                            / FP64_PEAK_TFLOPS) if fac_ms > 0 else 0.0,
+                                   "note": "algorithmic flops (no tile padding); MFMA and VALU FP64 share the pipe"},
                      "by_level_ms": [round(float(x), 4) for x in lvl_ms],
                      "by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
                                        for b, m in zip(lvl_bytes, lvl_ms)],

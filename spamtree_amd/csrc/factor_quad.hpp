@@ -490,10 +490,10 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   }
   STAMP(11);
   if constexpr (ISREF) {
-    // element slots per thread: m (m + 1) <= 128 * slots
-    // element slots per thread: m (m + 1) <= 128 * slots.  (One wave per unit without barriers was tried: slower.)
+    // element slots per thread: m (m + 1) <= 128 * slots.  
     if (Mmax <= 27) {
-      // one wave per unit, registers only (the jt = 0 waves sit on four different SIMDs); the partner waits at the barrier
+      // one wave per unit, registers only (the jt = 0 waves sit on four different SIMDs, which the elimination keeps busy:
+      // splitting the columns of L^{-1} over the unit's two waves would put two such waves on every SIMD)
       lds_barrier();   // R complete (both waves of the unit wrote parts of it)
       if (jt == 0) wave_chol_eliminate<27>(R, Ri, Mu, &s_fail[u], lane);
       lds_barrier();

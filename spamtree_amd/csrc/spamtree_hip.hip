@@ -570,8 +570,10 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
 // broadcasts + MM fused multiply-adds, about 400 cycles per pivot on an otherwise idle SIMD -- the team version's pivot
 // costs a workgroup barrier round trip (about 1.4k cycles with eight waves).  m <= MM <= 32; rows >= m behave as identity.
 //   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).  All 64 lanes must call.
-template <int MM>
+template <int MM, int J0 = 0, int J1 = MM>
 __device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm, int m, int *fail, int lane) {
+  // J0, J1: this wave produces columns [J0, J1) of L^{-1}.  Two waves can share one matrix: both run the (cheaper half of
+  // the) elimination of A redundantly -- no communication -- and each carries half of B's columns.
   double a[MM], b[MM];
   const bool row = lane < m;
 #pragma unroll
@@ -594,14 +596,15 @@ __device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm
 #pragma unroll
       for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
 #pragma unroll
-      for (int j = 0; j <= k; ++j) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
+      for (int j = J0; j < J1; ++j)
+        if (j <= k) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
     }
   }
   if (bad && lane == 0) *fail = 1;
   const double rs = rsqrt(dd);
   if (row) {
 #pragma unroll
-    for (int j = 0; j < MM; ++j)
+    for (int j = J0; j < J1; ++j)
       if (j <= lane) Bm[lane * CH_LD + j] = b[j] * rs;
   }
 }
