@@ -38,6 +38,8 @@ struct QuadArgs {
   const long long *gdesc;   // group descriptors of the level's first group onwards (Quad::g0 is relative to it)
   int gd_stride;
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
+  int wave_chol;   // the level's blocks have <= 27 rows: one-wave register elimination (a property of the LEVEL, so that a
+                   // unit's arithmetic does not depend on which units share its workgroup)
 };
 
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   STAMP(11);
   if constexpr (ISREF) {
     // element slots per thread: m (m + 1) <= 128 * slots.  
-    if (Mmax <= 27) {
+    if (A.wave_chol) {
       // one wave per unit, registers only (the jt = 0 waves sit on four different SIMDs, which the elimination keeps busy:
       // splitting the columns of L^{-1} over the unit's two waves would put two such waves on every SIMD)
       lds_barrier();   // R complete (both waves of the unit wrote parts of it)

@@ -2782,6 +2782,27 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       // pass 0 ignores ownership: its quad count decides eligibility, so that every rank of every world size takes
       // the same kernel for a level (results are then bit-identical across world sizes); pass 1 builds this rank's quads
       int nq_any = 0;
+      // units per workgroup on THIS rank: a sharded level with few owned groups takes smaller quads, so that its
+      // workgroups still cover the CUs (a workgroup of 2 / 1 units lives about 0.72 / 0.5 as long as one of 4; results do
+      // not depend on the grouping: every unit's arithmetic is its own)
+      int nu_max = h->quad_nu;
+      {
+        int owned = 0;
+        for (int k2 = 0; k2 < L.grp_count; ++k2) {
+          const Grp &Gq = h->grps[L.grp_first + k2];
+          if (g < h->cut || h->blk_owner[Gq.blk0] == h->rank) ++owned;
+        }
+        double best = 1e300;
+        const int cand[3] = {4, 2, 1};
+        const double tl[3] = {1.0, 0.72, 0.5};
+        for (int c = 0; c < 3; ++c) {
+          if (cand[c] > h->quad_nu) continue;
+          const double rounds = std::ceil((double)std::max(owned, 1) / (double)(cand[c] * h->sm_count));
+          if (rounds * tl[c] < best - 1e-9) { best = rounds * tl[c]; nu_max = cand[c]; }
+        }
+        const char *e = getenv("SPAMTREE_QUAD_UNITS");   // tests: force the units per workgroup (1, 2 or 4)
+        if (e && atoi(e) >= 1 && atoi(e) <= h->quad_nu) nu_max = atoi(e);
+      }
       for (int pass = 0; pass < 2; ++pass) {
         int k = 0;
         while (k < L.grp_count) {
@@ -2792,7 +2813,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
           Quad Qd;
           Qd.g0 = k; Qd.nu = 1; Qd.Jc = Jc; Qd.Pc = 0;
           for (int t = 0; t < Jc; ++t) Qd.Pc += h->blks[h->anc_idx[B0.anc_ptr + t]].m;
-          while (Qd.nu < h->quad_nu && k + Qd.nu < L.grp_count) {
+          while (Qd.nu < (pass == 0 ? h->quad_nu : nu_max) && k + Qd.nu < L.grp_count) {
             const Grp &G1 = h->grps[L.grp_first + k + Qd.nu];
             const Blk &B1 = h->blks[G1.blk0];
             if (B1.nanc != J || B1.isref != B0.isref) break;
@@ -3236,6 +3257,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
         F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p; F.ldS = L.q_ldS;
         F.gdesc = h->d_gdesc.p + (size_t)L.grp_first * h->gd_stride; F.gd_stride = h->gd_stride;
+        F.wave_chol = L.maxM <= 27 ? 1 : 0;
 #define QLAUNCH(NU_, NKX_, NKT_)                                                                                               \
   do {                                                                                                                         \
     if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp); \

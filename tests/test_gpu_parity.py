@@ -246,13 +246,15 @@ def test_running_posterior_means():
     hm.close()
 
 
-@pytest.mark.parametrize("gen", ["1", "3"])
+@pytest.mark.parametrize("gen", ["1", "3", "3:2", "3:1"])
 @pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[6], CASES[8]])
 def test_factor_kernel_generations(case, gen, monkeypatch):
     """Both phase-A kernels for column-group levels (SPAMTREE_FACTOR_KERNEL, read at st_create: 1 = k_factor_mfma
     everywhere, 3 = k_factor_quad; SPAMTREE_QUAD_MIN=1 makes even these tiny levels eligible) give the oracle's factors."""
+    gen, _, units = gen.partition(":")        # "3:2": k_factor_quad with at most 2 units per workgroup (default here: 4)
     monkeypatch.setenv("SPAMTREE_FACTOR_KERNEL", gen)
     monkeypatch.setenv("SPAMTREE_QUAD_MIN", "1")
+    monkeypatch.setenv("SPAMTREE_QUAD_UNITS", units or "4")
     pb = make_problem(seed=31, **case)
     rng = np.random.default_rng(6)
     w0 = rng.standard_normal(pb["n"])

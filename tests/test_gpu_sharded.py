@@ -19,13 +19,16 @@ def free_port():
 @pytest.mark.parametrize("side,q,quad_min", [(120, 1, None), (48, 3, None), (120, 1, "1")])
 def test_sharded_equals_single_process_bitwise(side, q, quad_min, tmp_path, monkeypatch):
     """quad_min = "1": even these small levels take k_factor_quad (SPAMTREE_QUAD_MIN, inherited by the spawned ranks),
-    whose quads are cut at ownership boundaries -- the results must not depend on how they are cut."""
+    whose quads are cut at ownership boundaries and sized by the rank's share of the level (here forced: 4 units per
+    workgroup in the single process, 2 with two ranks, 1 with three) -- the results must not depend on how they are cut."""
     if quad_min:
         monkeypatch.setenv("SPAMTREE_QUAD_MIN", quad_min)
+    units = {1: "4", 2: "2", 3: "1"}
     import torch.multiprocessing as mp
     from tests._sharded_worker import gpu_worker
     steps = 2
     for world in (1, 2, 3):
+        monkeypatch.setenv("SPAMTREE_QUAD_UNITS", units[world])
         mp.spawn(gpu_worker, args=(world, free_port(), side, q, str(tmp_path), steps), nprocs=world, join=True)
     ref = np.load(tmp_path / "res_1_0.npz")
     for world in (2, 3):

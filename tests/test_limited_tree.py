@@ -136,6 +136,7 @@ def test_limited_tree_quad_kernel(monkeypatch):
     """k_factor_quad on the limited tree (SPAMTREE_QUAD_MIN=1 makes these small levels eligible): siblings share their
     single parent's marginal factor; sibling leaf groups of different parents share nothing."""
     monkeypatch.setenv("SPAMTREE_QUAD_MIN", "1")
+    monkeypatch.setenv("SPAMTREE_QUAD_UNITS", "4")
     test_limited_tree_parity(LIMITED_CASES[1], False)
 
 
