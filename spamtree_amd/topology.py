@@ -218,6 +218,9 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
         parchi = np.column_stack([parchi, col])
         res_is_ref_l.append(0)
 
+    if len(res_is_ref_l) == 1:          # a single observed level is a reference level (make_tree.R:307-309: the rule is
+        res_is_ref_l[0] = 1             # applied BEFORE the level of the missing rows is appended, :317-413)
+
     # missing rows: their own last level, grouped by the block of the nearest deepest-level row
     if ix_mi.size:
         cur_ix = np.concatenate(all_ix); cur_block = np.concatenate(all_block); cur_res = np.concatenate(all_res)
@@ -237,8 +240,6 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
         res_is_ref_l.append(0)
 
     res_is_ref = np.asarray(res_is_ref_l, dtype=np.int64)
-    if res_is_ref.size == 1:
-        res_is_ref[:] = 1
     parchi = np.unique(parchi, axis=0)
     return TreeResult(ix=np.concatenate(all_ix), block=np.concatenate(all_block), res=np.concatenate(all_res),
                       parchi_map=parchi, res_is_ref=res_is_ref, thresholds=thresholds_list)

@@ -46,6 +46,12 @@ CASES = [
     dict(side=30, q=1, missing=0.1, cell_size=9, K=(3, 2)),
     dict(side=30, q=1, missing=0.0, tree_depth=2),
     dict(side=36, q=1, missing=0.05, cell_size=16, random_coords=True),
+    # degenerate sizes: one block only (a one-level tree: the exact GP), a few tiny ragged blocks with prediction blocks,
+    # two blocks of a trivariate problem, 4-row cells
+    dict(side=5, q=1, missing=0.0),
+    dict(side=7, q=1, missing=0.3),
+    dict(side=4, q=3, missing=0.2),
+    dict(side=9, q=2, missing=0.0, cell_size=4),
 ]
 
 
