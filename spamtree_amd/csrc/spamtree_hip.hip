@@ -3370,7 +3370,7 @@ extern "C" int st_comm_init(st_handle h, const void *unique_id) {
 
 extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik) {
   if (!h) return ST_ERR_USAGE;
-  if (h->world > 1) {
+  if (h->world > 1 || h->comm) {   // an attached communicator selects the exchange protocol even with one rank (tests)
     if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_factor_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
     int rc = st_factor_local(h, slot, theta, ntheta);
     if (rc) return rc;
@@ -3397,10 +3397,52 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
 // st_sample_w followed by st_loglik_w(slot) with ONE synchronisation (the sweep's failure word travels with the sums).
 extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot, double *loglik) {
   if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
-  if (h->world > 1) {
-    int rc = st_sample_w(h, z, seed, iter);
+  if (h->world > 1 || h->comm) {   // an attached communicator selects the exchange protocol even with one rank (tests)
+    if (!h->comm) {
+      int rc = st_sample_w(h, z, seed, iter);   // reports the missing communicator
+      if (rc) return rc;
+      return st_loglik_w(h, slot, loglik);
+    }
+    // Fused exchange: the log-density of a rank's own blocks needs w of its own subtrees and of the replicated top only,
+    // both current BEFORE the other ranks' rows arrive -- so phase C runs ahead of the exchange of w, and w and the
+    // log-density components travel in ONE grouped RCCL call, followed by ONE host synchronisation.
+    int rc = st_sample_w_local(h, z, seed, iter);
     if (rc) return rc;
-    return st_loglik_w(h, slot, loglik);
+    if (h->top_len > 0) NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
+    rc = st_sample_w_top(h);
+    if (rc) return rc;
+    void *pw = nullptr, *pc = nullptr;
+    int64_t lw = 0, lc = 0;
+    rc = st_mg_pack_w(h, &pw, &lw);         // own rows of w + this rank's failure word of the sweep
+    if (rc) return rc;
+    rc = st_loglik_local(h, slot);          // resets the failure word after the pack above (stream order)
+    if (rc) return rc;
+    rc = st_mg_pack_comps(h, slot, &pc, &lc);
+    if (rc) return rc;
+    NCHK(h, ncclGroupStart());
+    NCHK(h, ncclAllReduce(pw, pw, (size_t)lw, ncclDouble, ncclSum, h->comm, h->stream));
+    NCHK(h, ncclAllReduce(pc, pc, (size_t)lc, ncclDouble, ncclSum, h->comm, h->stream));
+    NCHK(h, ncclGroupEnd());
+    h->stats_valid = false; h->host_stats_valid = false;
+    const int nb = (int)h->n_blocks;
+    {
+      ProfScope ps(h, 3);
+      launch_sum2(h->stream, h->d_comm.p, h->d_comm.p + nb, nb, h->d_scalars.p + 8, h->d_scalars.p);
+    }
+    HCHK(h, hipGetLastError());
+    double s2[2], errw[64], errc[64];
+    HCHK(h, hipMemcpyAsync(h->d_w.p, h->d_tmp_n.p, (size_t)h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HCHK(h, hipMemcpyAsync(errw, h->d_tmp_n.p + h->n_all, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(h, hipMemcpyAsync(s2, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(h, hipMemcpyAsync(errc, h->d_comm.p + 2 * (size_t)nb, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(h, hipStreamSynchronize(h->stream));
+    int best = INT_MAX;
+    for (int r = 0; r < h->world; ++r) if (errw[r] > 0.5) best = std::min(best, (int)errw[r]);
+    if (best != INT_MAX) return best & 15;   // 10 / 11: the reference stops with "Error at gibbs_sample_w" (:1215-1217)
+    for (int r = 0; r < h->world; ++r) if (errc[r] > 0.5) best = std::min(best, (int)errc[r]);
+    if (best != INT_MAX) return best & 15;
+    if (loglik) *loglik = s2[0] + s2[1];
+    return ST_OK;
   }
   int rc = st_sample_w_local(h, z, seed, iter);
   if (rc) return rc;
@@ -3530,7 +3572,7 @@ extern "C" int st_mg_unpack_w(st_handle h) {
 
 extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
   if (!h) return ST_ERR_USAGE;
-  if (h->world > 1) {
+  if (h->world > 1 || h->comm) {   // an attached communicator selects the exchange protocol even with one rank (tests)
     if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_sample_w_local / st_mg_top_region / st_sample_w_top / st_mg_pack_w / st_mg_unpack_w"; return ST_ERR_USAGE; }
     int rc = st_sample_w_local(h, z, seed, iter);
     if (rc) return rc;
@@ -3581,7 +3623,7 @@ extern "C" int st_loglik_local(st_handle h, int slot) {
 }
 extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {
   if (!h) return ST_ERR_USAGE;
-  if (h->world > 1) {
+  if (h->world > 1 || h->comm) {   // an attached communicator selects the exchange protocol even with one rank (tests)
     if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_loglik_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
     int rc = st_loglik_local(h, slot);
     if (rc) return rc;

@@ -69,7 +69,7 @@ class Chain:
             raise SpamTreeError(f"stm_create failed ({rc}): {msg or self.lib.st_last_error(None).decode()}")
         self.h = C.c_void_p(self.lib.stm_handle(self.c))
         self.rank, self.world = int(rank), int(world)
-        if world > 1:
+        if world > 1 or unique_id is not None:   # a unique id with world == 1: the RCCL protocol path on a single rank (tests)
             buf = C.create_string_buffer(bytes(unique_id), 128)
             rc = self.lib.st_comm_init(self.h, C.cast(buf, C.c_void_p))
             if rc != 0:

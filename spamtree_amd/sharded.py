@@ -115,6 +115,36 @@ class ShardedSpamTreeMV(SpamTreeMV):
 
     gibbs_sample_w = deal_with_w
 
+    def deal_with_w_loglik(self, slot, z=None, seed=0, it=0):
+        """Sweep + log-density with ONE exchange after the replicated top: phase C of a rank's own blocks needs w of its
+        own subtrees and of the top only, so it runs before the other ranks' rows arrive (the order of the library's native
+        RCCL path, st_sample_w_loglik).  Returns the log-density."""
+        if self.world == 1 and not self.force_protocol:
+            self.deal_with_w(z, seed, it)
+            return self.get_loglik_w(slot)
+        if z is not None:
+            z = _f64(z)
+            self._check(self.lib.st_sample_w_local(self.h, _dp(z), 0, 0))
+        else:
+            self._check(self.lib.st_sample_w_local(self.h, None, int(seed), int(it)))
+        ptr, n = C.c_void_p(), C.c_int64()
+        self._check(self.lib.st_mg_top_region(self.h, C.byref(ptr), C.byref(n)))
+        self._allreduce(ptr.value, n.value)
+        self._check(self.lib.st_sample_w_top(self.h))
+        pw, nw, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._check(self.lib.st_mg_pack_w(self.h, C.byref(pw), C.byref(nw)))
+        self._check(self.lib.st_loglik_local(self.h, slot))
+        self._check(self.lib.st_mg_pack_comps(self.h, slot, C.byref(pc), C.byref(nc)))
+        self._allreduce(pw.value, nw.value)
+        self._allreduce(pc.value, nc.value)
+        rc = self._check(self.lib.st_mg_unpack_w(self.h))
+        if rc > 0:
+            raise SpamTreeError("Error at gibbs_sample_w")
+        ll = C.c_double(0.0)
+        self._check(self.lib.st_mg_finish(self.h, C.byref(ll)))
+        self.loglik_w[slot] = ll.value
+        return ll.value
+
     def shard_info(self):
         r, w, c = C.c_int32(), C.c_int32(), C.c_int32()
         ob, orow = C.c_int64(), C.c_int64()

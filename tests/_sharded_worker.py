@@ -84,8 +84,11 @@ def gpu_worker(rank, world, port, side, q, out_dir, steps):
     assert m.get_loglik_comps_w(0)
     res["ll_A"] = m.loglik_w[0]
     for it in range(steps):
-        m.deal_with_w(None, seed=5, it=it)
-        res[f"ll_C{it}"] = m.get_loglik_w(0)
+        if it % 2 == 1 and world > 1:             # the fused order: phase C before the exchange of w, one exchange for both
+            res[f"ll_C{it}"] = m.deal_with_w_loglik(0, None, seed=5, it=it)
+        else:
+            m.deal_with_w(None, seed=5, it=it)
+            res[f"ll_C{it}"] = m.get_loglik_w(0)
     th2 = wl["theta"] * 1.03
     m.theta_update(1, th2)
     assert m.get_loglik_comps_w(1)

@@ -51,3 +51,22 @@ def test_cpp_chain_steps_and_reports_state():
     assert st["iteration"] == 20 and np.all(np.isfinite(st["theta"])) and np.all(st["tausq_inv"] > 0)
     assert np.isfinite(st["loglik"]) and np.all(np.isfinite(ch.get_w()))
     ch.close()
+
+
+def test_native_rccl_protocol_single_rank():
+    """The library's own RCCL path (st_comm_init: pack -> ncclAllReduce on the launch stream -> deterministic finish) with a
+    one-rank communicator gives the chain of the plain single-GPU path bit for bit.  (More than one rank per GPU is not
+    possible with RCCL; the multi-rank protocol itself is covered through gloo in tests/test_gpu_sharded.py.)"""
+    from spamtree_amd import fit
+    pb = make_problem(side=40, q=1, seed=3, missing=0.05)
+    states = []
+    for uid in (None, fit.make_unique_id()):
+        ch = fit.Chain(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"], pb["res_is_ref"],
+                       pb["parents"], pb["children"], False, pb["block_names"], pb["block_groups"], pb["indexing"],
+                       pb["bounds"], pb["theta"], np.zeros(pb["p"]), 0.1, 0.01 * np.eye(4), seed=5, unique_id=uid)
+        ch.step(12)
+        st = ch.state()
+        states.append((st["theta"].copy(), st["tausq_inv"].copy(), float(st["loglik"]), ch.get_w().copy()))
+        ch.close()
+    a, b = states
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
