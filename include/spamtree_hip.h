@@ -185,6 +185,12 @@ int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len);
 int st_sample_w_top(st_handle h);
 int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len);
 int st_mg_unpack_w(st_handle h);
+/* all-gather form of the last step of phase B (half the traffic of the all-reduce of n doubles; what the native path uses):
+ * every rank's slice of the receive buffer holds its owned rows in device order + its failure word, `count_per_rank`
+ * doubles each (the same on all ranks); the replicated top is sampled identically everywhere and does not travel.
+ *   st_mg_gather_w_pack -> all-gather(send = recv + rank * count, recv) -> st_mg_gather_w_unpack      (code 0/10/11) */
+int st_mg_gather_w_pack(st_handle h, void **send_ptr, void **recv_ptr, int64_t *count_per_rank);
+int st_mg_gather_w_unpack(st_handle h);
 
 #ifdef __cplusplus
 }

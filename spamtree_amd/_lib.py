@@ -64,6 +64,8 @@ SIGNATURES = {
     "st_sample_w_top": (C.c_int, [H]),
     "st_mg_pack_w": (C.c_int, [H, C.POINTER(C.c_void_p), c_ip]),
     "st_mg_unpack_w": (C.c_int, [H]),
+    "st_mg_gather_w_pack": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_ip]),
+    "st_mg_gather_w_unpack": (C.c_int, [H]),
     "st_cross_covariance_ag10": (C.c_int, [c_dp, c_ip, C.c_int64, c_dp, c_ip, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32,
                                            C.c_int32, c_dp]),
     "st_summary_reset": (C.c_int, [H]),

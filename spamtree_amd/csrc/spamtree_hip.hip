@@ -2247,6 +2247,10 @@ struct st_handle_s {
   DevBuf<int> d_owngrp, d_ownslow;
   DevBuf<unsigned char> d_rowmask, d_blkmask; // 1 = this rank contributes the entry to a sum-with-zeros exchange
   DevBuf<double> d_comm;                      // 2*n_blocks + 64 doubles
+  DevBuf<double> d_gather;                    // all-gather of w: world x gather_cnt (a rank's owned rows in device order + its failure word)
+  DevBuf<int> d_gidx;                         // device row of every slot of d_gather (-1: padding / the failure word)
+  int gather_cnt = 1;
+  DevBuf<double> d_gerr;                      // the ranks' failure words after the all-gather (64)
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
   std::vector<std::pair<long long, long long>> top_zero;   // sub-ranges of it owned by other ranks
   bool ext_stream = false;
@@ -2377,7 +2381,7 @@ extern "C" int st_destroy(st_handle h) {
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
   h->d_twin.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
-  h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
+  h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -2983,6 +2987,26 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   { std::vector<int> a = h->own_obs_slow; if (a.empty()) a.push_back(0); CCHK(h->d_ownslow.upload(a)); }
   CCHK(h->d_rowmask.upload(rowmask)); CCHK(h->d_blkmask.upload(blkmask));
   CCHK(h->d_comm.alloc((size_t)2 * nb + 64));
+  {
+    // all-gather of w: every rank's owned rows (blocks below the cut, prediction blocks included), in device order; the
+    // replicated top is sampled identically everywhere and does not travel
+    std::vector<std::vector<int>> rows_of(h->world);
+    for (int i = 0; i < nb; ++i) {
+      const int o = h->blk_owner[i];
+      if (o < 0) continue;
+      const Blk &B = h->blks[i];
+      for (int r2 = 0; r2 < B.m; ++r2) rows_of[o].push_back((int)(B.row0 + r2));
+    }
+    size_t mx = 0;
+    for (auto &v : rows_of) mx = std::max(mx, v.size());
+    h->gather_cnt = (int)mx + 1;   // last slot: the rank's failure word
+    std::vector<int> gi((size_t)h->world * h->gather_cnt, -1);
+    for (int r = 0; r < h->world; ++r)
+      for (size_t i2 = 0; i2 < rows_of[r].size(); ++i2) gi[(size_t)r * h->gather_cnt + i2] = rows_of[r][i2];
+    CCHK(h->d_gidx.upload(gi));
+    CCHK(h->d_gather.alloc(gi.size()));
+    CCHK(h->d_gerr.alloc(64));
+  }
   CCHK(h->d_w.alloc(n)); CCHK(h->d_xb.alloc(n)); CCHK(h->d_z.alloc(n)); CCHK(h->d_tmp_n.alloc(n + 64));
   CCHK(hipMemset(h->d_w.p, 0, n * sizeof(double)));
   CCHK(hipMemset(h->d_xb.p, 0, n * sizeof(double)));
@@ -3221,6 +3245,20 @@ __global__ void k_pack_comps(const double *logdet, const double *loglik, const u
   }
   if (i < world) buf[2 * nb + i] = (i == rank && err[0] != INT_MAX) ? (double)err[0] : 0.0;
 }
+// all-gather form of the exchange of w: a rank's slice of the gather buffer = its owned rows + its failure word
+__global__ void k_gather_pack(const double *w, const int *idx, int cnt, const int *err, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt - 1) { const int r = idx[i]; out[i] = r >= 0 ? w[r] : 0.0; }
+  else if (i == cnt - 1) out[i] = err[0] != INT_MAX ? (double)err[0] : 0.0;
+}
+__global__ void k_gather_unpack(const double *recv, const int *idx, int cnt, long long total, double *w, double *errs) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= total) return;
+  const int i = (int)(j % cnt);
+  if (i == cnt - 1) { errs[j / cnt] = recv[j]; return; }
+  const int r = idx[j];
+  if (r >= 0) w[r] = recv[j];
+}
 __global__ void k_pack_w(const double *w, const unsigned char *mask, long long n, const int *err, int rank, int world, double *buf) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) buf[i] = mask[i] ? w[i] : 0.0;
@@ -3395,6 +3433,7 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
 }
 
 // st_sample_w followed by st_loglik_w(slot) with ONE synchronisation (the sweep's failure word travels with the sums).
+static int gather_w_scatter(st_handle h);
 extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot, double *loglik) {
   if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
   if (h->world > 1 || h->comm) {   // an attached communicator selects the exchange protocol even with one rank (tests)
@@ -3411,18 +3450,20 @@ extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, u
     if (h->top_len > 0) NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
     rc = st_sample_w_top(h);
     if (rc) return rc;
-    void *pw = nullptr, *pc = nullptr;
+    void *pw = nullptr, *pr = nullptr, *pc = nullptr;
     int64_t lw = 0, lc = 0;
-    rc = st_mg_pack_w(h, &pw, &lw);         // own rows of w + this rank's failure word of the sweep
+    rc = st_mg_gather_w_pack(h, &pw, &pr, &lw);   // own rows of w + this rank's failure word of the sweep
     if (rc) return rc;
     rc = st_loglik_local(h, slot);          // resets the failure word after the pack above (stream order)
     if (rc) return rc;
     rc = st_mg_pack_comps(h, slot, &pc, &lc);
     if (rc) return rc;
     NCHK(h, ncclGroupStart());
-    NCHK(h, ncclAllReduce(pw, pw, (size_t)lw, ncclDouble, ncclSum, h->comm, h->stream));
+    NCHK(h, ncclAllGather(pw, pr, (size_t)lw, ncclDouble, h->comm, h->stream));
     NCHK(h, ncclAllReduce(pc, pc, (size_t)lc, ncclDouble, ncclSum, h->comm, h->stream));
     NCHK(h, ncclGroupEnd());
+    rc = gather_w_scatter(h);
+    if (rc) return rc;
     h->stats_valid = false; h->host_stats_valid = false;
     const int nb = (int)h->n_blocks;
     {
@@ -3431,8 +3472,7 @@ extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, u
     }
     HCHK(h, hipGetLastError());
     double s2[2], errw[64], errc[64];
-    HCHK(h, hipMemcpyAsync(h->d_w.p, h->d_tmp_n.p, (size_t)h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HCHK(h, hipMemcpyAsync(errw, h->d_tmp_n.p + h->n_all, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(h, hipMemcpyAsync(errw, h->d_gerr.p, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HCHK(h, hipMemcpyAsync(s2, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HCHK(h, hipMemcpyAsync(errc, h->d_comm.p + 2 * (size_t)nb, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HCHK(h, hipStreamSynchronize(h->stream));
@@ -3570,6 +3610,41 @@ extern "C" int st_mg_unpack_w(st_handle h) {
   return best == INT_MAX ? ST_OK : (best & 15);
 }
 
+// all-gather form (half the traffic of the all-reduce of n doubles): pack -> all-gather(recv, count per rank) -> unpack
+extern "C" int st_mg_gather_w_pack(st_handle h, void **send_ptr, void **recv_ptr, int64_t *count_per_rank) {
+  if (!h) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  const int cnt = h->gather_cnt;
+  double *mine = h->d_gather.p + (size_t)h->rank * cnt;
+  hipLaunchKernelGGL(k_gather_pack, dim3((cnt + NT - 1) / NT), dim3(NT), 0, h->stream, h->d_w.p, h->d_gidx.p + (size_t)h->rank * cnt, cnt,
+                     h->d_err.p, mine);
+  HCHK(h, hipGetLastError());
+  if (send_ptr) *send_ptr = mine;
+  if (recv_ptr) *recv_ptr = h->d_gather.p;
+  if (count_per_rank) *count_per_rank = cnt;
+  return ST_OK;
+}
+static int gather_w_scatter(st_handle h) {   // launches only: rows into w, failure words into d_gerr
+  const long long total = (long long)h->world * h->gather_cnt;
+  hipLaunchKernelGGL(k_gather_unpack, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, h->stream, h->d_gather.p, h->d_gidx.p, h->gather_cnt,
+                     total, h->d_w.p, h->d_gerr.p);
+  HCHK(h, hipGetLastError());
+  return ST_OK;
+}
+extern "C" int st_mg_gather_w_unpack(st_handle h) {
+  if (!h) return ST_ERR_USAGE;
+  h->stats_valid = false; h->host_stats_valid = false;
+  HCHK(h, hipSetDevice(h->device));
+  int rc = gather_w_scatter(h);
+  if (rc) return rc;
+  double errw[64];
+  HCHK(h, hipMemcpyAsync(errw, h->d_gerr.p, h->world * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  int best = INT_MAX;
+  for (int r = 0; r < h->world; ++r) if (errw[r] > 0.5) best = std::min(best, (int)errw[r]);
+  return best == INT_MAX ? ST_OK : (best & 15);
+}
+
 extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
   if (!h) return ST_ERR_USAGE;
   if (h->world > 1 || h->comm) {   // an attached communicator selects the exchange protocol even with one rank (tests)
@@ -3579,12 +3654,12 @@ extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t
     if (h->top_len > 0) NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
     rc = st_sample_w_top(h);
     if (rc) return rc;
-    void *ptr = nullptr;
-    int64_t len = 0;
-    rc = st_mg_pack_w(h, &ptr, &len);
+    void *snd = nullptr, *rcv = nullptr;
+    int64_t cnt = 0;
+    rc = st_mg_gather_w_pack(h, &snd, &rcv, &cnt);
     if (rc) return rc;
-    NCHK(h, ncclAllReduce(ptr, ptr, (size_t)len, ncclDouble, ncclSum, h->comm, h->stream));
-    return st_mg_unpack_w(h);
+    NCHK(h, ncclAllGather(snd, rcv, (size_t)cnt, ncclDouble, h->comm, h->stream));
+    return st_mg_gather_w_unpack(h);
   }
   int rc = st_sample_w_local(h, z, seed, iter);
   if (rc) return rc;

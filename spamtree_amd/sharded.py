@@ -42,6 +42,7 @@ class ShardedSpamTreeMV(SpamTreeMV):
         self.torch = torch
         self.dist = dist
         self.force_protocol = bool(force_protocol)   # run the local/exchange/finish steps even with one rank (tests)
+        self.use_allreduce_w = bool(kw.pop("allreduce_w", False))   # exchange w by all-reduce (sum with zeros) instead of all-gather
         rank = dist.get_rank() if dist is not None else 0
         world = dist.get_world_size() if dist is not None else 1
         self.backend = dist.get_backend() if dist is not None else None
@@ -66,6 +67,29 @@ class ShardedSpamTreeMV(SpamTreeMV):
             self.dist.all_reduce(host)
             t.copy_(host)
             torch.cuda.synchronize()
+
+    # ---- all-gather of a library-owned receive buffer (world slices of `cnt` doubles; this rank's slice is filled)
+    def _allgather(self, recv_ptr, cnt):
+        if self.dist is None or (self.world == 1 and not self.force_protocol):
+            return
+        torch = self.torch
+        t = torch.as_tensor(_DevArray(recv_ptr, self.world * cnt), device=torch.device("cuda", self.device_index))
+        if self.backend == "nccl":
+            self.dist.all_gather_into_tensor(t, t[self.rank * cnt: (self.rank + 1) * cnt].clone())
+        else:
+            self._check(self.lib.st_synchronize(self.h))
+            host = t.cpu()
+            parts = [torch.empty(cnt, dtype=host.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, host[self.rank * cnt: (self.rank + 1) * cnt].clone())
+            t.copy_(torch.cat(parts))
+            torch.cuda.synchronize()
+
+    def _exchange_w(self):
+        """Last step of phase B: every rank's owned rows of w (+ its failure word) by all-gather."""
+        snd, rcv, cnt = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._check(self.lib.st_mg_gather_w_pack(self.h, C.byref(snd), C.byref(rcv), C.byref(cnt)))
+        self._allgather(rcv.value, cnt.value)
+        return self._check(self.lib.st_mg_gather_w_unpack(self.h))
 
     def _exchange_comps(self, slot):
         ptr, n = C.c_void_p(), C.c_int64()
@@ -107,9 +131,12 @@ class ShardedSpamTreeMV(SpamTreeMV):
         self._check(self.lib.st_mg_top_region(self.h, C.byref(ptr), C.byref(n)))
         self._allreduce(ptr.value, n.value)
         self._check(self.lib.st_sample_w_top(self.h))
-        self._check(self.lib.st_mg_pack_w(self.h, C.byref(ptr), C.byref(n)))
-        self._allreduce(ptr.value, n.value)
-        rc = self._check(self.lib.st_mg_unpack_w(self.h))
+        if self.use_allreduce_w:        # the all-reduce form of the same exchange (st_mg_pack_w / st_mg_unpack_w)
+            self._check(self.lib.st_mg_pack_w(self.h, C.byref(ptr), C.byref(n)))
+            self._allreduce(ptr.value, n.value)
+            rc = self._check(self.lib.st_mg_unpack_w(self.h))
+        else:
+            rc = self._exchange_w()
         if rc > 0:
             raise SpamTreeError("Error at gibbs_sample_w")
 
@@ -131,13 +158,13 @@ class ShardedSpamTreeMV(SpamTreeMV):
         self._check(self.lib.st_mg_top_region(self.h, C.byref(ptr), C.byref(n)))
         self._allreduce(ptr.value, n.value)
         self._check(self.lib.st_sample_w_top(self.h))
-        pw, nw, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
-        self._check(self.lib.st_mg_pack_w(self.h, C.byref(pw), C.byref(nw)))
+        snd, rcv, cnt, pc, nc = C.c_void_p(), C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._check(self.lib.st_mg_gather_w_pack(self.h, C.byref(snd), C.byref(rcv), C.byref(cnt)))
         self._check(self.lib.st_loglik_local(self.h, slot))
         self._check(self.lib.st_mg_pack_comps(self.h, slot, C.byref(pc), C.byref(nc)))
-        self._allreduce(pw.value, nw.value)
+        self._allgather(rcv.value, cnt.value)
         self._allreduce(pc.value, nc.value)
-        rc = self._check(self.lib.st_mg_unpack_w(self.h))
+        rc = self._check(self.lib.st_mg_gather_w_unpack(self.h))
         if rc > 0:
             raise SpamTreeError("Error at gibbs_sample_w")
         ll = C.c_double(0.0)

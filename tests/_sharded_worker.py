@@ -77,7 +77,7 @@ def gpu_worker(rank, world, port, side, q, out_dir, steps):
     m = ShardedSpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
                           wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
                           wl["indexing"], np.zeros(wl["n"]), np.array([-0.5, 0.2, 0.4]), wl["theta"], 1.0 / 0.15,
-                          device=0, dist=dist if world > 1 else None)
+                          device=0, dist=dist if world > 1 else None, allreduce_w=(world == 3))   # both forms of the w exchange
     rng = np.random.default_rng(3)
     m.set_w(rng.standard_normal(wl["n"]))
     res = {}
