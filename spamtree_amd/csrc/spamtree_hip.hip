@@ -570,6 +570,54 @@ __device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int 
 // broadcasts + MM fused multiply-adds, about 400 cycles per pivot on an otherwise idle SIMD -- the team version's pivot
 // costs a workgroup barrier round trip (about 1.4k cycles with eight waves).  m <= MM <= 32; rows >= m behave as identity.
 //   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).  All 64 lanes must call.
+__device__ __forceinline__ double wave_allsum(double x);
+// The block-Gibbs draw w = L^{-T} (L^{-1} b + z), S = L L' (spamtree_model.cpp:1054, 1086: Sigi_chol = L^{-1},
+// w = Sigi_chol' (Sigi_chol Smu + z)), by ONE wave without ever forming L^{-1}: lane i keeps row i of S in registers;
+// the right-hand side rides along the elimination as one more column (forward substitution for free); the backward
+// substitution costs one wave sum per row.  No LDS traffic, no barriers inside.  m <= MM <= 32.  All 64 lanes must call.
+//   Sm: LDS, row stride CH_LD, lower triangle valid.  bm, zm, wout: LDS vectors (wout may alias bm or zm).
+template <int MM>
+__device__ __forceinline__ void wave_chol_solve(const double *Sm, const double *bm, const double *zm, double *wout, int m, int *fail, int lane) {
+  double a[MM];
+  const bool row = lane < m;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) a[j] = (row && j <= lane) ? Sm[min(lane, 31) * CH_LD + j] : (j == lane ? 1.0 : 0.0);
+  double c = row ? bm[min(lane, 31)] : 0.0;   // running right-hand side: ends as L_ii y_i
+  const double zi = row ? zm[min(lane, 31)] : 0.0;
+  double dd = 1.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < MM; ++k) {
+    if (k < m) {   // wave-uniform
+      const double d = readlane_f64(a[k], k);
+      bad = bad || !(d > 0.0);
+      dd = lane == k ? d : dd;
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      const double f = lane > k ? -a[k] * rd : 0.0;
+#pragma unroll
+      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
+      c = fma(f, readlane_f64(c, k), c);
+    }
+  }
+  if (bad && lane == 0) *fail = 1;
+  // a[k] of lane i > k is now L_ik L_kk, the diagonal d_i = L_ii^2, c = L_ii y_i
+  const double rs = rsqrt(dd);
+  const double t = fma(c, rs, zi);      // y_i + z_i
+  double w = 0.0;
+#pragma unroll
+  for (int k = MM - 1; k >= 0; --k) {
+    if (k < m) {   // wave-uniform
+      const double sk = wave_allsum(lane > k ? a[k] * w : 0.0);          // sum_{i > k} L_ik L_kk w_i
+      const double rk = readlane_f64(rs, k);
+      const double wk = (readlane_f64(t, k) - rk * sk) * rk;
+      w = lane == k ? wk : w;
+    }
+  }
+  if (row) wout[lane] = w;
+}
+
 template <int MM, int J0 = 0, int J1 = MM>
 __device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm, int m, int *fail, int lane) {
   // J0, J1: this wave produces columns [J0, J1) of L^{-1}.  Two waves can share one matrix: both run the (cheaper half of
@@ -1491,19 +1539,23 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
   if (refgrp) {
     // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I]: two small matrix-vector products
     // instead of a forward and a backward substitution (m barrier steps each)
-    if (M <= 22) team_chol_eliminate<2, NT>(S, Li, M, M, av, &s_fail, tid);
-    else if (M <= 27) team_chol_eliminate<3, NT>(S, Li, M, M, av, &s_fail, tid);
-    else team_chol_eliminate<5, NT>(S, Li, M, M, av, &s_fail, tid);
-    if (tid < M) {
-      double a = zc[tid];
-      for (int j = 0; j <= tid; ++j) a += Li[tid * CH_LD + j] * bv[j];
-      ev[tid] = a;
-    }
-    __syncthreads();
-    if (tid < M) {
-      double a = 0.0;
-      for (int i = tid; i < M; ++i) a += Li[i * CH_LD + tid] * ev[i];
-      wv[P + tid] = a;
+    if (M <= 27) {
+      // one wave, registers only (wave_chol_solve): the other waves wait
+      __syncthreads();   // S, bv complete
+      if (tid < 64) wave_chol_solve<27>(S, bv, zc, wv + P, M, &s_fail, tid);
+    } else {
+      team_chol_eliminate<5, NT>(S, Li, M, M, av, &s_fail, tid);
+      if (tid < M) {
+        double a = zc[tid];
+        for (int j = 0; j <= tid; ++j) a += Li[tid * CH_LD + j] * bv[j];
+        ev[tid] = a;
+      }
+      __syncthreads();
+      if (tid < M) {
+        double a = 0.0;
+        for (int i = tid; i < M; ++i) a += Li[i * CH_LD + tid] * ev[i];
+        wv[P + tid] = a;
+      }
     }
   }
   __syncthreads();
@@ -1648,12 +1700,12 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
     const double *row = A.panels + s_rowoff[r] + oa;
     const double *wa = wv + oa;
     double a = 0.0;
-    for (int j0 = 0; j0 < ma; j0 += 8) {
-      double x[8];
+    for (int j0 = 0; j0 < ma; j0 += 16) {   // two batches of loads for the usual 25-row ancestor
+      double x[16];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
+      for (int jj = 0; jj < 16; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+      for (int jj = 0; jj < 16; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
     }
     seg[t * 32 + r] = a;
   }
@@ -1698,21 +1750,26 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
     // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I] (scratch: the pivot cells live after
     // the segment sums, which stay intact)
     double *pub = seg + 32 * J;
-    if (M <= 22) team_chol_eliminate<2, NT>(S, S, M, M, pub, &s_fail, tid);
-    else if (M <= 27) team_chol_eliminate<3, NT>(S, S, M, M, pub, &s_fail, tid);
-    else team_chol_eliminate<5, NT>(S, S, M, M, pub, &s_fail, tid);
-    if (tid < M) {
-      double a = zc[tid];
-      for (int j = 0; j <= tid; ++j) a += S[tid * CH_LD + j] * bv[j];
-      ev[tid] = a;
+    if (M <= 27) {
+      // one wave, registers only: elimination with the right-hand side riding along, backward substitution by wave sums
+      __syncthreads();   // S, bv complete
+      if (tid < 64) wave_chol_solve<27>(S, bv, zc, wv + P, M, &s_fail, tid);
+      __syncthreads();
+    } else {
+      team_chol_eliminate<5, NT>(S, S, M, M, pub, &s_fail, tid);
+      if (tid < M) {
+        double a = zc[tid];
+        for (int j = 0; j <= tid; ++j) a += S[tid * CH_LD + j] * bv[j];
+        ev[tid] = a;
+      }
+      __syncthreads();
+      if (tid < M) {
+        double a = 0.0;
+        for (int i = tid; i < M; ++i) a += S[i * CH_LD + tid] * ev[i];
+        wv[P + tid] = a;
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (tid < M) {
-      double a = 0.0;
-      for (int i = tid; i < M; ++i) a += S[i * CH_LD + tid] * ev[i];
-      wv[P + tid] = a;
-    }
-    __syncthreads();
     if (tid < M) {
       const int i = tid;
       A.w[G.row0 + i] = wv[P + i];
