@@ -17,7 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "d_wavechol_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py
+PMC_SUMMARY = "e_final_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_PEAK_TFLOPS = 78.6    # FP64 matrix = FP64 vector peak; both run on ONE pipe per SIMD (profiles/r01/micro_f64_pipes.log)
 
