@@ -18,6 +18,7 @@ CASES = {
     "q1_n625": dict(side=25, q=1, seed=101, missing=0.1),
     "q1_n1600_random": dict(side=40, q=1, seed=102, random_coords=True),
     "q3_n588": dict(side=14, q=3, seed=103, missing=0.15),
+    "q1_n900_limited": dict(side=30, q=1, seed=104, missing=0.1, limited_tree=True),   # limited_tree = TRUE (tree_dep.cpp:133-186)
 }
 
 
@@ -30,7 +31,10 @@ def csr(lists):
 
 def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
+    only = set(sys.argv[1:])                     # python tests/golden/make_golden.py [case ...]: default all
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         pb = make_problem(**kw)
         rng = np.random.default_rng(kw["seed"] + 1000)
         w0 = rng.standard_normal(pb["n"])
@@ -43,6 +47,7 @@ def main():
                  gix_block=pb["gix_block"], res_is_ref=pb["res_is_ref"], block_names=pb["block_names"],
                  block_groups=pb["block_groups"], indexing_ptr=ip, indexing_idx=ii, parents_ptr=pp, parents_idx=pi,
                  children_ptr=cp, children_idx=ci, theta=pb["theta"], beta=beta, tausq=np.array(tausq), w0=w0,
+                 limited_tree=np.array(int(bool(kw.get("limited_tree", False)))),
                  loglik_A=np.array(om.param_data.loglik_w), logdet_comps=om.param_data.logdetCi_comps.copy(),
                  loglik_comps=om.param_data.loglik_w_comps.copy())
         # a few per-block caches
