@@ -1,4 +1,4 @@
-"""GPU: 2 and 3 processes share ONE problem on device 0 (gloo exchange); every result must equal the single-process
+"""GPU: 2, 3 and 4 processes share ONE problem on device 0 (gloo exchange); every result must equal the single-process
 run bit for bit (ownership by subtree, exchanges are sums with zeros)."""
 import socket
 
@@ -23,15 +23,18 @@ def test_sharded_equals_single_process_bitwise(side, q, quad_min, tmp_path, monk
     workgroup in the single process, 2 with two ranks, 1 with three) -- the results must not depend on how they are cut."""
     if quad_min:
         monkeypatch.setenv("SPAMTREE_QUAD_MIN", quad_min)
-    units = {1: "4", 2: "2", 3: "1"}
+    units = {1: "4", 2: "2", 3: "1", 4: None}     # None: the library's own choice for the rank's share of a level
     import torch.multiprocessing as mp
     from tests._sharded_worker import gpu_worker
     steps = 2
-    for world in (1, 2, 3):
-        monkeypatch.setenv("SPAMTREE_QUAD_UNITS", units[world])
+    for world in (1, 2, 3, 4):
+        if units[world] is None:
+            monkeypatch.delenv("SPAMTREE_QUAD_UNITS", raising=False)
+        else:
+            monkeypatch.setenv("SPAMTREE_QUAD_UNITS", units[world])
         mp.spawn(gpu_worker, args=(world, free_port(), side, q, str(tmp_path), steps), nprocs=world, join=True)
     ref = np.load(tmp_path / "res_1_0.npz")
-    for world in (2, 3):
+    for world in (2, 3, 4):
         rows = 0
         for rank in range(world):
             r = np.load(tmp_path / f"res_{world}_{rank}.npz")
