@@ -91,6 +91,11 @@ int st_get_xb(st_handle h, double *xb);                    /* n_all */
  * slot 0 = param_data, 1 = alter_data.  Returns 0 (the reference's `true`) or 1/2/3 (`false`, errtype);
  * *loglik = data.loglik_w (undefined on failure).  theta has ntheta = 3q + (q>2?3:1) + q(q-1)/2 entries. */
 int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik);
+/* optional: start phase A of the latency-bound top levels ahead of time -- they depend on theta only (their blocks'
+ * quadratic forms are redone with the current w afterwards) -- on a second stream, e.g. before the sweep; the next
+ * st_factor / st_factor_local for the same slot and theta picks the result up.  Identical results; a no-op when the tree
+ * does not qualify or SPAMTREE_ASYNC_TOP=0.  (The proposal of spamtree_fit.cpp:211-229 does not depend on the sweep.) */
+int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta);
 
 /* ---- accept_make_change (spamtree_model.cpp:1432-1435): swap the two cache slots */
 int st_swap(st_handle h);

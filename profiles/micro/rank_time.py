@@ -67,7 +67,20 @@ for world in (1, 2, 4, 8):
             fn(arg)
         lib.st_synchronize(h)
         res[name] = (time.perf_counter() - t0) / 20 * 1e3
-    tot = sum(res.values())
+    # whole iterations (B, C, A back to back), without and with phase A of the top levels started ahead (st_factor_begin)
+    lib.st_factor_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+    for name, ahead in (("iter", False), ("iter_ahead", True)):
+        for rep in range(23):
+            if rep == 3:
+                lib.st_synchronize(h)
+                t0 = time.perf_counter()
+            if ahead:
+                lib.st_factor_begin(h, 1, _dp(th), th.size)
+            sample(rep); loglik(0); factor(1)
+        lib.st_synchronize(h)
+        res[name] = (time.perf_counter() - t0) / 20 * 1e3
+    print(f"world {world}: whole iteration {res['iter']:.3f} ms; with the top levels ahead of time {res['iter_ahead']:.3f} ms")
+    tot = res["A"] + res["B"] + res["C"]
     print(f"world {world}: rank 0 per iteration  A {res['A']:.3f}  B {res['B']:.3f}  C {res['C']:.3f}  sum {tot:.3f} ms"
           f"  -> ideal strong-scaling speed-up without collectives: {0 if world == 1 else base / tot:.2f}x" if world > 1 else
           f"world 1: A {res['A']:.3f}  B {res['B']:.3f}  C {res['C']:.3f}  sum {tot:.3f} ms")

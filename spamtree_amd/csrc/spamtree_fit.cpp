@@ -225,17 +225,14 @@ extern "C" int stm_init(stm_chain c) {
 static int step_w_theta(stm_chain c) {
   const uint32_t m = (uint32_t)c->m;
   int rc;
-  if (c->sample_w) {
-    rc = st_sample_w_loglik(c->h, nullptr, c->seed, m, 0, &c->loglik[0]);   // deal_with_w + get_loglik_w (:182-185)
-    if (rc > 0) { c->err = "Error at gibbs_sample_w"; return rc; }
-    if (rc < 0) { c->err = st_last_error(c->h); return rc; }
-    c->current_loglik = c->loglik[0];
-  }
+  const int k = c->k;
+  RAMAdapt &am = c->am;
+  std::vector<double> U(k), np(k);
   if (c->sample_theta) {
-    const int k = c->k;
-    RAMAdapt &am = c->am;
+    // The proposal (:211-229) needs only theta, the adaptation state and its own normals (counter-based streams: drawing
+    // them before the sweep's changes no value) -- so the factorisation of the latency-bound top levels for it can start
+    // now and run under the sweep (st_factor_begin; results identical)
     am.count_proposal();
-    std::vector<double> U(k), np(k);
     for (int i = 0; i < k; ++i) U[i] = c->rng.normal(i, 0, m, 1);
     for (int j = 0; j < k; ++j) {                       // par_huvtransf_back(par_huvtransf_fwd(param) + paramsd * U)
       double f = logit(c->param[j], c->bounds[j], c->bounds[k + j]);
@@ -246,6 +243,18 @@ static int step_w_theta(stm_chain c) {
       if (np[j] < c->bounds[j]) np[j] = c->bounds[j] + 1e-10;
       if (np[j] > c->bounds[k + j]) np[j] = c->bounds[k + j] - 1e-10;
     }
+    if (c->sample_w) {
+      rc = st_factor_begin(c->h, 1, np.data(), k);
+      if (rc < 0) { c->err = st_last_error(c->h); return rc; }
+    }
+  }
+  if (c->sample_w) {
+    rc = st_sample_w_loglik(c->h, nullptr, c->seed, m, 0, &c->loglik[0]);   // deal_with_w + get_loglik_w (:182-185)
+    if (rc > 0) { c->err = "Error at gibbs_sample_w"; return rc; }
+    if (rc < 0) { c->err = st_last_error(c->h); return rc; }
+    c->current_loglik = c->loglik[0];
+  }
+  if (c->sample_theta) {
     c->theta_alt = np;
     double new_ll = c->loglik[1];
     rc = st_factor(c->h, 1, np.data(), k, &new_ll);

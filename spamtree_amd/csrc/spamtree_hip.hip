@@ -2308,6 +2308,15 @@ struct st_handle_s {
   DevBuf<int> d_gidx;                         // device row of every slot of d_gather (-1: padding / the failure word)
   int gather_cnt = 1;
   DevBuf<double> d_gerr;                      // the ranks' failure words after the all-gather (64)
+  // phase A of the latency-bound top levels ahead of time (st_factor_begin): they depend on theta only -- except for the
+  // blocks' quadratic forms, redone with the current w afterwards -- and run on a second stream under the sweep
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_top = nullptr, ev_main = nullptr;
+  DevBuf<int> d_err2, d_toplist;
+  int n_toplist = 0, g_top = 0;
+  bool async_top = false, top_pending = false, prof_suspend = false;
+  int top_phys = -1;
+  std::vector<double> top_theta;
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
   std::vector<std::pair<long long, long long>> top_zero;   // sub-ranges of it owned by other ranks
   bool ext_stream = false;
@@ -2399,7 +2408,7 @@ struct ProfScope {
   // mode 1: every launch is bracketed; mode 2: only the whole-phase bracket of phase A (level == -2), one pair of events
   ProfScope(st_handle_s *h_, int fam, int level = -1, int count = 1) : h(h_) {
     r.fam = fam; r.level = level; r.count = count; r.a = r.b = nullptr;
-    const bool on = level == -2 ? h->prof == 2 : h->prof == 1;
+    const bool on = !h->prof_suspend && (level == -2 ? h->prof == 2 : h->prof == 1);
     if (on) { r.a = prof_event(h); r.b = prof_event(h); (void)hipEventRecord(r.a, h->stream); }
   }
   ~ProfScope() {
@@ -2438,7 +2447,10 @@ extern "C" int st_destroy(st_handle h) {
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
   h->d_twin.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
-  h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_sum_w.free(); h->d_sum_yhat.free();
+  h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_err2.free(); h->d_toplist.free();
+  if (h->ev_top) (void)hipEventDestroy(h->ev_top);
+  if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -3140,6 +3152,33 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     QATTR(4, 50, 13); QATTR(4, 44, 11); QATTR(4, 38, 10); QATTR(4, 32, 8);
 #undef QATTR
   }
+  {
+    // top levels that st_factor_begin may run ahead: the leading levels on k_factor_mfma (no global scratch), when every
+    // level of the tree is on the column-group path (the generic kernels share one scratch arena between phases)
+    h->g_top = 0;
+    bool all_fast = !h->limited && !h->force_generic;
+    for (int g = 0; g < n_actual; ++g) all_fast = all_fast && h->levels[g].fast;
+    if (all_fast) {
+      while (h->g_top < n_actual && !(h->factor_gen == 3 && h->levels[h->g_top].q_nkx > 0)) ++h->g_top;
+      if (h->g_top >= n_actual) h->g_top = 0;   // nothing would be left for the main stream to hide it under
+    }
+    // default: on sharded runs only -- there the top levels are a fixed cost of every rank (0.19 of ~0.8 ms of phase A per
+    // rank at n = 1e6 on 8 GPUs) and the sweep leaves most of the chip idle while they would run; on one GPU the sweep
+    // fills the chip and the gain is 1.4 % (SPAMTREE_ASYNC_TOP=1 / 0 forces either)
+    const char *e = getenv("SPAMTREE_ASYNC_TOP");
+    h->async_top = h->g_top > 0 && (e ? e[0] != '0' : h->world > 1);
+    std::vector<int> tl;
+    for (int b : h->own_obs_list) if (h->blks[b].level < h->g_top) tl.push_back(b);
+    h->n_toplist = (int)tl.size();
+    if (tl.empty()) tl.push_back(0);
+    CCHK(h->d_toplist.upload(tl));
+    CCHK(h->d_err2.alloc(2));
+    if (h->async_top) {
+      CCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+      CCHK(hipEventCreateWithFlags(&h->ev_top, hipEventDisableTiming));
+      CCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    }
+  }
   (void)hipGetLastError();
 #undef CCHK
   h->prof_level_ms.assign(2 * n_actual, 0.0);
@@ -3322,18 +3361,22 @@ __global__ void k_pack_w(const double *w, const unsigned char *mask, long long n
   if (i < world) buf[n + i] = (i == rank && err[0] != INT_MAX) ? (double)err[0] : 0.0;
 }
 
-static int factor_launch(st_handle h, int phys, const CovPar &cp) {
+// levels [g_lo, g_hi); `st` / `errflag`: the launch stream and failure word (st_factor_begin: the second stream, d_err2)
+static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, int g_hi = INT_MAX, hipStream_t st = nullptr, int *errflag = nullptr) {
+  g_hi = std::min(g_hi, h->n_actual_groups);
+  if (!st) st = h->stream;
+  if (!errflag) errflag = h->d_err.p;
   int n_launch = 0;
-  for (int g = 0; g < h->n_actual_groups; ++g) n_launch += ((h->levels[g].fast ? h->levels[g].gown_n : h->levels[g].own_n) != 0);
+  for (int g = g_lo; g < g_hi; ++g) n_launch += ((h->levels[g].fast ? h->levels[g].gown_n : h->levels[g].own_n) != 0);
   ProfScope phase(h, 0, -2, n_launch);   // profile mode 2: the phase's launches between ONE pair of events (mean launch = total / launches)
-  if (h->limited && !h->twin_list.empty()) {
+  if (g_lo == 0 && h->limited && !h->twin_list.empty()) {
     MarginalArgs M;
     M.blks = h->d_blks.p; M.list = h->d_twin.p; M.nlist = (int)h->twin_list.size(); M.cx = h->d_cx.p; M.cy = h->d_cy.p; M.mv = h->d_mv.p;
     M.panels = h->d_panels[phys].p; M.errflag = h->d_err.p; M.maxM = h->twin_maxM;
     const size_t lds = (size_t)2 * h->twin_maxM * h->twin_maxM * sizeof(double);
     hipLaunchKernelGGL(k_marginal_invchol, dim3(std::min(M.nlist, 8 * h->sm_count)), dim3(NT), lds, h->stream, M, cp);
   }
-  for (int g = 0; g < h->n_actual_groups; ++g) {
+  for (int g = g_lo; g < g_hi; ++g) {
     const LevelInfo &L = h->levels[g];
     if ((L.fast ? L.gown_n : L.own_n) == 0) continue;
     FactorArgs A;
@@ -3365,10 +3408,10 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
         std::memset(&F, 0, sizeof(F));
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first + L.gown_lo; F.ngrp = L.gown_n;
         F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
-        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p;
+        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = errflag;
         F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
-        hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, h->stream, F, cp);
+        hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, st, F, cp);
       } else if (L.bigmfma && h->factor_gen == 3) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
         if (L.maxM <= 48) hipLaunchKernelGGL((k_factor_bigmfma<3, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
@@ -3382,6 +3425,35 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp) {
   return ST_OK;
 }
 
+__global__ void k_merge_err(int *err, const int *err2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && err2[0] < err[0]) err[0] = err2[0];
+}
+
+// Phase A of the top levels ahead of time, on the second stream: call before the sweep with the theta st_factor /
+// st_factor_local will be given next for the same slot.  A no-op when the tree does not qualify (or SPAMTREE_ASYNC_TOP=0).
+extern "C" int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta) {
+  if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  if (!h->async_top) return ST_OK;
+  HCHK(h, hipSetDevice(h->device));
+  CovPar cp;
+  int rc = make_covpar(h, theta, ntheta, &cp);
+  if (rc) return rc;
+  if (h->top_pending) HCHK(h, hipStreamWaitEvent(h->stream2, h->ev_top, 0));
+  HCHK(h, hipEventRecord(h->ev_main, h->stream));          // everything issued so far (the previous iteration) comes first
+  HCHK(h, hipStreamWaitEvent(h->stream2, h->ev_main, 0));
+  const int init[2] = {INT_MAX, 0};
+  HCHK(h, hipMemcpyAsync(h->d_err2.p, init, 2 * sizeof(int), hipMemcpyHostToDevice, h->stream2));
+  const int phys = h->slot_map[slot];
+  h->prof_suspend = true;   // not timed: the launches overlap the sweep on another stream
+  rc = factor_launch(h, phys, cp, 0, h->g_top, h->stream2, h->d_err2.p);
+  h->prof_suspend = false;
+  if (rc) return rc;
+  HCHK(h, hipEventRecord(h->ev_top, h->stream2));
+  h->top_pending = true; h->top_phys = phys; h->top_theta.assign(theta, theta + ntheta);
+  return ST_OK;
+}
+static int fix_top_comps(st_handle h, int phys);
+
 extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int ntheta) {
   if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
@@ -3392,7 +3464,21 @@ extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int n
   if (slot == 0) h->gram_valid = false;
   rc = reset_err(h);
   if (rc) return rc;
-  return factor_launch(h, h->slot_map[slot], cp);
+  const int phys = h->slot_map[slot];
+  bool reuse = false;
+  if (h->top_pending) {
+    HCHK(h, hipStreamWaitEvent(h->stream, h->ev_top, 0));   // the top levels are done (or at least out of the way) before anything below
+    reuse = h->top_phys == phys && (int)h->top_theta.size() == ntheta && std::equal(theta, theta + ntheta, h->top_theta.begin());
+    h->top_pending = false;
+  }
+  if (!reuse) return factor_launch(h, phys, cp);
+  rc = factor_launch(h, phys, cp, h->g_top);
+  if (rc) return rc;
+  rc = fix_top_comps(h, phys);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_merge_err, dim3(1), dim3(64), 0, h->stream, h->d_err.p, h->d_err2.p);
+  HCHK(h, hipGetLastError());
+  return ST_OK;
 }
 
 extern "C" int st_mg_pack_comps(st_handle h, int slot, void **dev_ptr, int64_t *len) {
@@ -3751,6 +3837,21 @@ extern "C" int st_loglik_local(st_handle h, int slot) {
   }
   HCHK(h, hipGetLastError());
   HCHK(h, reset_err(h) == ST_OK ? hipSuccess : hipErrorUnknown);
+  return ST_OK;
+}
+// the quadratic forms of the top blocks with the CURRENT w (st_factor_begin ran them with the w of the sweep's start)
+static int fix_top_comps(st_handle h, int phys) {
+  if (h->n_toplist == 0) return ST_OK;
+  int maxP = 0, maxM = 0;
+  for (int g = 0; g < h->g_top; ++g) { maxP = std::max(maxP, h->levels[g].maxP); maxM = std::max(maxM, h->levels[g].maxM); }
+  LoglikArgs A;
+  A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_toplist.p; A.nlist = h->n_toplist;
+  A.panels = h->d_panels[phys].p; A.w = h->d_w.p; A.loglik_c = h->d_loglik[phys].p; A.maxP = maxP; A.maxM = maxM;
+  {
+    ProfScope ps(h, 0, h->g_top > 0 ? h->g_top - 1 : 0);
+    hipLaunchKernelGGL(k_loglik, dim3(A.nlist), dim3(NT), lds_loglik_bytes(maxP, maxM), h->stream, A);
+  }
+  HCHK(h, hipGetLastError());
   return ST_OK;
 }
 extern "C" int st_loglik_w(st_handle h, int slot, double *loglik) {

@@ -70,3 +70,24 @@ def test_native_rccl_protocol_single_rank():
         ch.close()
     a, b = states
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("async_top", ["1", "0"])
+def test_cpp_driver_with_top_levels_ahead_of_time(async_top, monkeypatch):
+    """st_factor_begin: the C++ driver starts phase A of the top levels for the proposal before the sweep, on a second
+    stream (SPAMTREE_QUAD_MIN=1 gives this small tree quad levels below, hence top levels to run ahead).  Chains with and
+    without it (SPAMTREE_ASYNC_TOP=0) equal the oracle's."""
+    from oracle import spamtree_oracle as so
+    from spamtree_amd import fit
+    monkeypatch.setenv("SPAMTREE_QUAD_MIN", "1")
+    monkeypatch.setenv("SPAMTREE_QUAD_UNITS", "4")
+    monkeypatch.setenv("SPAMTREE_ASYNC_TOP", async_top)
+    pb = make_problem(side=40, q=1, seed=21, missing=0.05)
+    k = pb["theta"].size
+    kw = dict(mcmc_keep=3, mcmc_burn=40, mcmc_thin=1, adapting=True, seed=7, main_verbose=False)
+    ref = so.spamtree_mv_mcmc(*args_of(pb, k), **kw)
+    got = fit.spamtree_mv_mcmc(*args_of(pb, k), **kw)
+    assert relerr(got["theta_mcmc"], ref["theta_mcmc"]) < 1e-8
+    assert relerr(got["tausq_mcmc"], ref["tausq_mcmc"]) < 1e-8 and relerr(got["beta_mcmc"], ref["beta_mcmc"]) < 1e-8
+    for i in range(3):
+        assert relerr(np.asarray(got["w_mcmc"][i]).reshape(-1), ref["w_mcmc"][i]) < 1e-8
