@@ -53,14 +53,18 @@ def test_cpp_chain_steps_and_reports_state():
     ch.close()
 
 
-def test_native_rccl_protocol_single_rank():
+def test_native_rccl_protocol_single_rank(monkeypatch):
     """The library's own RCCL path (st_comm_init: pack -> ncclAllReduce on the launch stream -> deterministic finish) with a
     one-rank communicator gives the chain of the plain single-GPU path bit for bit.  (More than one rank per GPU is not
     possible with RCCL; the multi-rank protocol itself is covered through gloo in tests/test_gpu_sharded.py.)"""
     from spamtree_amd import fit
     pb = make_problem(side=40, q=1, seed=3, missing=0.05)
     states = []
+    monkeypatch.setenv("SPAMTREE_QUAD_MIN", "1")        # quad levels below, so that there are top levels to run ahead
+    monkeypatch.setenv("SPAMTREE_QUAD_UNITS", "4")
     for uid in (None, fit.make_unique_id()):
+        # the communicator run also starts phase A of the top levels ahead of time, as sharded runs do by default
+        monkeypatch.setenv("SPAMTREE_ASYNC_TOP", "0" if uid is None else "1")
         ch = fit.Chain(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"], pb["res_is_ref"],
                        pb["parents"], pb["children"], False, pb["block_names"], pb["block_groups"], pb["indexing"],
                        pb["bounds"], pb["theta"], np.zeros(pb["p"]), 0.1, 0.01 * np.eye(4), seed=5, unique_id=uid)
