@@ -197,6 +197,8 @@ def main():
                      "by_level_ms": [round(float(x), 4) for x in lvl_ms],
                      "by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
                                        for b, m in zip(lvl_bytes, lvl_ms)],
+                     "by_level_frac": [round(float(b / (m * 1e-3) / 1e9 / HBM_PEAK_GBS), 3) if m > 0 else 0.0
+                                       for b, m in zip(lvl_bytes, lvl_ms)],   # the same ratio per launch (one kernel per level)
                      "sample_by_level_ms": [round(float(x), 4) for x in smp_ms],
                      "sample_by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
                                               for b, m in zip(smp_bytes, smp_ms)],
