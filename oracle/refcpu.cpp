@@ -160,7 +160,7 @@ struct Data {  // SpamTreeMVData, tree_utils.h:63-102
 struct RefModel {
   long long n_all = 0;
   int q = 1, p = 1, nb = 0, n_actual = 0;
-  bool reference_distance = false, quirks = true;
+  bool reference_distance = false, quirks = true, limited = false;
   std::vector<double> y, X, cx, cy, w, XB, tausq_inv_long, tausq_inv;
   std::vector<int> mv;
   std::vector<char> avail;
@@ -277,7 +277,14 @@ struct RefModel {
             Mat L;
             if (chol_lower(Kcc, L)) {
               d.Rcc_invchol[u] = inv_trimatl(L);
-              if (!children[u].empty()) {
+              if (!children[u].empty() && limited) {
+                Mat Kuu = covmat(iu, iu), Lu;                     // :901-903  Kxx_inv(u) = inv_sympd(Kcc)
+                if (chol_lower(Kuu, Lu)) { d.Kxx_inv[u] = gram_lower(inv_trimatl(Lu)); d.has_updated[u] = 1; }
+                else {
+#pragma omp critical
+                  errtype = 2;
+                }
+              } else if (!children[u].empty()) {
                 // invchol_block_inplace_direct (tree_utils.cpp:194-208) + dense Gram (:904-906)
                 Mat &O = d.Kxx_invchol[u];
                 const Mat &LAi = d.Kxx_invchol[last_par];
@@ -457,7 +464,8 @@ void *refcpu_create(long long n_all, int q, int p, long long n_blocks, int n_gro
 #endif
   RefModel *M = new RefModel();
   M->n_all = n_all; M->q = q; M->p = p; M->nb = (int)n_blocks;
-  M->reference_distance = reference_distance != 0; M->quirks = reference_quirks != 0;
+  M->reference_distance = reference_distance != 0; M->quirks = (reference_quirks & 1) != 0;
+  M->limited = (reference_quirks & 2) != 0;   // limited_tree = TRUE (spamtree_model.cpp:901-903): single parents, Kxx_inv(u) = inv_sympd(K_uu)
   M->cp.q = q; M->cp.ncb = q > 2 ? 3 : 1;
   M->y.assign(y, y + n_all); M->X.assign(X, X + (size_t)n_all * p);
   M->cx.assign(coords, coords + n_all); M->cy.assign(coords + n_all, coords + 2 * n_all);

@@ -47,7 +47,7 @@ def _csr(x):
 
 class RefCpu:
     def __init__(self, y, X, coords, mv_id, res_is_ref, parents, children, block_names, block_groups, indexing,
-                 reference_distance=False, reference_quirks=True, threads=0):
+                 reference_distance=False, reference_quirks=True, threads=0, limited_tree=False):
         self.lib = load()
         self.y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
         self.X = np.asfortranarray(np.asarray(X, dtype=np.float64))
@@ -62,7 +62,7 @@ class RefCpu:
         ip = lambda a: a.ctypes.data_as(_ip)   # noqa: E731
         self.h = self.lib.refcpu_create(self.n, self.q, self.p, self.nb, int(arrs[1].size), self._d(self.y), self._d(self.X),
                                         self._d(self.coords), *[ip(a) for a in arrs], int(reference_distance),
-                                        int(reference_quirks), int(threads))
+                                        int(bool(reference_quirks)) | (2 if limited_tree else 0), int(threads))   # bit 1: limited_tree
         self.idx_ptr, self.par_ptr = arrs[4], arrs[6]
         self.isref = None
 

@@ -47,12 +47,10 @@ def test_oracle_reproduces_golden(path):
 def test_refcpu_reproduces_golden(path):
     from oracle.refcpu import RefCpu
     g = np.load(path)
-    if limited(g):
-        pytest.skip("oracle/refcpu restates the full-ancestor tree only")
     q = int(np.unique(g["mv_id"]).size)
     rc = RefCpu(g["y"], g["X"], g["coords"], g["mv_id"], g["res_is_ref"], (g["parents_ptr"], g["parents_idx"]),
                 (g["children_ptr"], g["children_idx"]), g["block_names"], g["block_groups"],
-                (g["indexing_ptr"], g["indexing_idx"]), threads=2)
+                (g["indexing_ptr"], g["indexing_idx"]), threads=2, limited_tree=limited(g))
     rc.set_w(g["w0"]); rc.set_beta(np.tile(g["beta"][:, None], (1, q))); rc.set_tausq_inv(1.0 / float(g["tausq"]))
     code, ll = rc.factor(0, g["theta"])
     assert code == 0 and abs(ll - float(g["loglik_A"])) <= REL * abs(ll)

@@ -1,7 +1,8 @@
 """limited_tree = TRUE (/root/reference/src/tree_dep.cpp:133-186, /root/reference/src/spamtree_model.cpp:901-903,
 1275-1278): every block has ONE parent, Kxx_inv(u) = inv_sympd(K_uu).
 
-CPU part: the edge builder's contract and the oracle's limited branch against dense brute force.
+CPU part: the edge builder's contract and the oracle's limited branch against dense brute force (the OpenMP restatement
+oracle/refcpu reproduces the limited golden fixture in tests/test_golden.py).
 GPU part: the HIP path (st_options.reserved bit 1: marginal chain factors, k_marginal_invchol) against the oracle.
 """
 import math
