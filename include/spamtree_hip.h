@@ -94,8 +94,9 @@ int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *lo
 /* optional: start phase A of the latency-bound top levels ahead of time -- they depend on theta only (their blocks'
  * quadratic forms are redone with the current w afterwards) -- on a second stream, e.g. before the sweep; the next
  * st_factor / st_factor_local for the same slot and theta picks the result up.  Identical results; a no-op when the tree
- * does not qualify or SPAMTREE_ASYNC_TOP=0.  (The proposal of spamtree_fit.cpp:211-229 does not depend on the sweep.) */
+ * does not qualify (column-group levels above a k_factor_quad level) or SPAMTREE_ASYNC_TOP=0.  (The proposal of spamtree_fit.cpp:211-229 does not depend on the sweep.) */
 int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta);
+int st_factor_ahead_levels(st_handle h);   /* how many leading levels st_factor_begin runs ahead (0: none) */
 
 /* ---- accept_make_change (spamtree_model.cpp:1432-1435): swap the two cache slots */
 int st_swap(st_handle h);

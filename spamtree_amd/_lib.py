@@ -35,6 +35,7 @@ SIGNATURES = {
     "st_get_xb": (C.c_int, [H, c_dp]),
     "st_factor": (C.c_int, [H, C.c_int, c_dp, C.c_int, c_dp]),
     "st_factor_begin": (C.c_int, [H, C.c_int, c_dp, C.c_int]),
+    "st_factor_ahead_levels": (C.c_int, [H]),
     "st_swap": (C.c_int, [H]),
     "st_sample_w": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32]),
     "st_loglik_w": (C.c_int, [H, C.c_int, c_dp]),

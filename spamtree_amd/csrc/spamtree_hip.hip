@@ -2406,14 +2406,15 @@ struct ProfScope {
   st_handle_s *h;
   st_handle_s::ProfRec r;
   // mode 1: every launch is bracketed; mode 2: only the whole-phase bracket of phase A (level == -2), one pair of events
-  ProfScope(st_handle_s *h_, int fam, int level = -1, int count = 1) : h(h_) {
+  hipStream_t st;
+  ProfScope(st_handle_s *h_, int fam, int level = -1, int count = 1, hipStream_t st_ = nullptr) : h(h_), st(st_ ? st_ : h_->stream) {
     r.fam = fam; r.level = level; r.count = count; r.a = r.b = nullptr;
-    const bool on = !h->prof_suspend && (level == -2 ? h->prof == 2 : h->prof == 1);
-    if (on) { r.a = prof_event(h); r.b = prof_event(h); (void)hipEventRecord(r.a, h->stream); }
+    const bool on = level == -2 ? (h->prof == 2 && !h->prof_suspend) : h->prof == 1;
+    if (on) { r.a = prof_event(h); r.b = prof_event(h); (void)hipEventRecord(r.a, st); }
   }
   ~ProfScope() {
     if (r.a && r.b) {
-      (void)hipEventRecord(r.b, h->stream);
+      (void)hipEventRecord(r.b, st);
       h->prof_pending.push_back(r);
       if (h->prof_pending.size() > 8192) prof_harvest(h);
     }
@@ -3162,11 +3163,10 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       while (h->g_top < n_actual && !(h->factor_gen == 3 && h->levels[h->g_top].q_nkx > 0)) ++h->g_top;
       if (h->g_top >= n_actual) h->g_top = 0;   // nothing would be left for the main stream to hide it under
     }
-    // default: on sharded runs only -- there the top levels are a fixed cost of every rank (0.19 of ~0.8 ms of phase A per
-    // rank at n = 1e6 on 8 GPUs) and the sweep leaves most of the chip idle while they would run; on one GPU the sweep
-    // fills the chip and the gain is 1.4 % (SPAMTREE_ASYNC_TOP=1 / 0 forces either)
+    // the top levels are a fixed cost (0.19 ms at n = 1e6: a quarter of a rank's phase A on 8 GPUs, 40 % of phase A at
+    // n = 1e5); at n = 1e6 on one GPU the sweep fills the chip and the gain is 1.5 % (SPAMTREE_ASYNC_TOP=0 turns it off)
     const char *e = getenv("SPAMTREE_ASYNC_TOP");
-    h->async_top = h->g_top > 0 && (e ? e[0] != '0' : h->world > 1);
+    h->async_top = h->g_top > 0 && !(e && e[0] == '0');
     std::vector<int> tl;
     for (int b : h->own_obs_list) if (h->blks[b].level < h->g_top) tl.push_back(b);
     h->n_toplist = (int)tl.size();
@@ -3386,7 +3386,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
     A.panels = h->d_panels[phys].p; A.logdet_c = h->d_logdet[phys].p; A.loglik_c = h->d_loglik[phys].p;
     A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
     {
-      ProfScope ps(h, 0, g);
+      ProfScope ps(h, 0, g, 1, st);
       if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) {
         QuadArgs F;
         std::memset(&F, 0, sizeof(F));
@@ -3431,6 +3431,7 @@ __global__ void k_merge_err(int *err, const int *err2) {
 
 // Phase A of the top levels ahead of time, on the second stream: call before the sweep with the theta st_factor /
 // st_factor_local will be given next for the same slot.  A no-op when the tree does not qualify (or SPAMTREE_ASYNC_TOP=0).
+extern "C" int st_factor_ahead_levels(st_handle h) { return (h && h->async_top) ? h->g_top : 0; }
 extern "C" int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta) {
   if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
   if (!h->async_top) return ST_OK;

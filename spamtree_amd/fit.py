@@ -123,6 +123,10 @@ class Chain:
         k = nl.value
         return ms[:k].copy(), by[:k].copy(), ms[k: 2 * k].copy(), by[k: 2 * k].copy()
 
+    def factor_ahead_levels(self):
+        """Leading levels whose phase A the driver starts before the sweep (st_factor_begin); 0 = none."""
+        return int(self.lib.st_factor_ahead_levels(self.h))
+
     def synchronize(self):
         self.lib.st_synchronize(self.h)
 
