@@ -197,9 +197,9 @@ def main():
                      "whole_iteration_GBps": alg["total"] / (dt / args.steps) / 1e9,
                      # secondary view: the kernel's HBM traffic is ~5x below its algorithmic bytes (chain panels come from
                      # L2 / Infinity Cache), what saturates is the SIMDs' FP64 pipe -- useful flops of phase A over its time
-                     "fp64_pipe": {"achieved": alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_levels * 1e-3) / 1e12
+                     "fp64_pipe": {"achieved": alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_bracket * 1e-3) / 1e12
                                    if fac_ms > 0 else 0.0, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": (alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_levels * 1e-3) / 1e12
+                                   "frac": (alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_bracket * 1e-3) / 1e12
                                             / FP64_PEAK_TFLOPS) if fac_ms > 0 else 0.0,
                                    "note": "algorithmic flops (no tile padding); MFMA and VALU FP64 share the pipe"},
                      "by_level_ms": [round(float(x), 4) for x in lvl_ms],
