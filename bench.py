@@ -68,6 +68,44 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
             "measured_it_per_s_at_sample": its / dt, "sample_n": int(wl["n"])}
 
 
+class ExternalChain:
+    """Fallback for N > 1 when the library's own RCCL communicator cannot be set up: the same sharded phases with the
+    collectives issued through torch.distributed on torch's stream (spamtree_amd/sharded.py) and the Python host driver
+    (spamtree_amd/mcmc.py).  Same results; a Python loop instead of the C++ driver."""
+
+    def __init__(self, wl, dist, device, k):
+        import ctypes as C
+        from spamtree_amd import mcmc
+        from spamtree_amd.sharded import ShardedSpamTreeMV
+        self._C = C
+        self.mt = ShardedSpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
+                                    wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"],
+                                    wl["block_groups"], wl["indexing"], np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"],
+                                    1.0 / 0.1, device=device, dist=dist)
+        self.pc = mcmc.Chain(self.mt, wl["bounds"], 0.01 * np.eye(k), seed=2021, adapting=True)
+
+    def step(self, n=1):
+        for _ in range(int(n)):
+            self.pc.step()
+
+    def state(self):
+        return {"accept_ratio": float(self.pc.adaptivemc.accept_ratio)}
+
+    def profile_levels_all(self):
+        C = self._C
+        nl = C.c_int32(); ms = np.zeros(128); by = np.zeros(128)
+        self.mt.lib.st_profile_levels(self.mt.h, C.byref(nl), ms.ctypes.data_as(C.POINTER(C.c_double)),
+                                      by.ctypes.data_as(C.POINTER(C.c_double)), 128)
+        kk = nl.value
+        return ms[:kk].copy(), by[:kk].copy(), ms[kk: 2 * kk].copy(), by[kk: 2 * kk].copy()
+
+    def factor_ahead_levels(self):
+        return 0          # the Python driver does not call st_factor_begin
+
+    def __getattr__(self, name):      # algorithmic_bytes, profile, profile_get, profile_levels, synchronize, shard_info, close
+        return getattr(self.mt, name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +117,7 @@ def main():
     ap.add_argument("--missing", type=str, default="", help="per-outcome drop probabilities, e.g. 0.1,0.3,0.5 (config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-side", type=int, default=316, help="grid side of the bounded CPU-baseline sample")
+    ap.add_argument("--external", action="store_true", help="force the torch.distributed + Python-driver fallback path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,10 +148,28 @@ def main():
     k = wl["theta"].size
     # the C++ host driver (spamtree_amd/csrc/spamtree_fit.cpp) steps the chain: w sweep, log-density, RAM-adaptive MH with a
     # full re-factorisation of the proposal slot, tausq and beta draws
-    chain = fit.Chain(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
-                      wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
-                      wl["indexing"], wl["bounds"], wl["theta"], np.zeros(wl["p"]), 0.1, 0.01 * np.eye(k), seed=2021,
-                      adapting=True, device=local_rank, rank=rank, world=world, unique_id=uid)
+    chain, native_err = None, ""
+    if not args.external:
+        try:
+            chain = fit.Chain(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
+                              wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
+                              wl["indexing"], wl["bounds"], wl["theta"], np.zeros(wl["p"]), 0.1, 0.01 * np.eye(k), seed=2021,
+                              adapting=True, device=local_rank, rank=rank, world=world, unique_id=uid)
+        except Exception as exc:      # noqa: BLE001  (N > 1 only: every rank must agree before falling back)
+            if world == 1:
+                raise
+            native_err = repr(exc)
+    ok = torch.tensor([1 if chain is not None else 0], device="cuda", dtype=torch.int32)
+    if dist is not None:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    host_path = "C++ host driver, collectives issued by the library (RCCL on its stream)" if world > 1 else "C++ host driver"
+    if int(ok.item()) == 0:
+        if chain is not None:
+            chain.close()
+        if rank == 0 and native_err:
+            print("bench.py: native RCCL path unavailable (" + native_err + "); falling back to torch.distributed", file=sys.stderr)
+        chain = ExternalChain(wl, dist, local_rank, k)
+        host_path = "Python host driver, collectives through torch.distributed (fallback path)"
     model = chain
     n_blocks = int(np.asarray(wl["block_names"]).size)
     t_setup = time.time() - t_setup
@@ -184,7 +241,7 @@ def main():
                                f"covariance, default tree (cell_size=25, K=(2,2)), {n_blocks} blocks, "
                                "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH"
                                + (f"; sharded over {world} GPUs by subtree, RCCL all-reduce exchanges" if world > 1 else ""),
-                   "n": int(wl["n"]), "q": args.q, "blocks": int(n_blocks), "levels": int(n_levels),
+                   "n": int(wl["n"]), "q": args.q, "blocks": int(n_blocks), "levels": int(n_levels), "host_path": host_path,
                    "mh_accept_ratio": float(chain.state()["accept_ratio"]),
                    "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
                        alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},
