@@ -2315,6 +2315,8 @@ struct st_handle_s {
   DevBuf<int> d_err2, d_toplist;
   int n_toplist = 0, g_top = 0;
   bool async_top = false, top_pending = false, prof_suspend = false;
+  hipEvent_t ev_stats = nullptr;
+  bool stats_on_stream2 = false;   // the statistics kernels of the current (w, XB) are in flight on the second stream
   int top_phys = -1;
   std::vector<double> top_theta;
   long long top_off = 0, top_len = 0;         // message records of the cut level inside `acc`
@@ -2421,6 +2423,16 @@ struct ProfScope {
   }
 };
 
+// w or XB is about to change: the cached statistics die; a reduction still in flight on the second stream finishes first
+static void invalidate_stats(st_handle_s *h) {
+  if (h->stats_on_stream2) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamWaitEvent(h->stream, h->ev_stats, 0);
+    h->stats_on_stream2 = false;
+  }
+  h->stats_valid = false; h->host_stats_valid = false;
+}
+
 static size_t lds_factor_bytes(int maxP, int maxM, int maxMa, int SR, bool big) {
   size_t dbl = (size_t)3 * (maxP + maxM) + 3 * (size_t)maxM + (size_t)SR * maxP;
   size_t bytes = dbl * 8 + (size_t)((maxP + maxM + 1) & ~1) * 4;
@@ -2451,6 +2463,7 @@ extern "C" int st_destroy(st_handle h) {
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_err2.free(); h->d_toplist.free();
   if (h->ev_top) (void)hipEventDestroy(h->ev_top);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
+  if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
   if (h->stream2) (void)hipStreamDestroy(h->stream2); h->d_sum_w.free(); h->d_sum_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
@@ -3177,6 +3190,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       CCHK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
       CCHK(hipEventCreateWithFlags(&h->ev_top, hipEventDisableTiming));
       CCHK(hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+      CCHK(hipEventCreateWithFlags(&h->ev_stats, hipEventDisableTiming));
     }
   }
   (void)hipGetLastError();
@@ -3205,7 +3219,7 @@ static int download_rows(st_handle h, const double *src, double *dst) {
 
 extern "C" int st_set_w(st_handle h, const double *w) {
   if (!h || !w) return ST_ERR_USAGE;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
   return upload_rows(h, w, h->d_w.p);
 }
@@ -3221,7 +3235,7 @@ extern "C" int st_get_xb(st_handle h, double *xb) {
 }
 extern "C" int st_set_beta(st_handle h, const double *Bcoeff) {
   if (!h || !Bcoeff) return ST_ERR_USAGE;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
   HCHK(h, hipMemcpyAsync(h->d_B.p, Bcoeff, (size_t)h->p * h->q * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
@@ -3454,6 +3468,19 @@ extern "C" int st_factor_begin(st_handle h, int slot, const double *theta, int n
   return ST_OK;
 }
 static int fix_top_comps(st_handle h, int phys);
+static int run_stats(st_handle h, hipStream_t st);
+// The beta / tausq statistics of the iteration need the sweep's w and the current XB only: when a proposal is about to be
+// factorised they start on the second stream and run under phase A (the driver asks for them after the Metropolis step).
+static int stats_begin(st_handle h) {
+  if (!h->stream2 || h->stats_valid) return ST_OK;
+  HCHK(h, hipEventRecord(h->ev_main, h->stream));           // w of the sweep is final at this point of the main stream
+  HCHK(h, hipStreamWaitEvent(h->stream2, h->ev_main, 0));
+  int rc = run_stats(h, h->stream2);
+  if (rc) return rc;
+  HCHK(h, hipEventRecord(h->ev_stats, h->stream2));
+  h->stats_on_stream2 = true;
+  return ST_OK;
+}
 
 extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int ntheta) {
   if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
@@ -3466,6 +3493,7 @@ extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int n
   rc = reset_err(h);
   if (rc) return rc;
   const int phys = h->slot_map[slot];
+  if (slot == 1) { rc = stats_begin(h); if (rc) return rc; }
   bool reuse = false;
   if (h->top_pending) {
     HCHK(h, hipStreamWaitEvent(h->stream, h->ev_top, 0));   // the top levels are done (or at least out of the way) before anything below
@@ -3608,7 +3636,7 @@ extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, u
     NCHK(h, ncclGroupEnd());
     rc = gather_w_scatter(h);
     if (rc) return rc;
-    h->stats_valid = false; h->host_stats_valid = false;
+    invalidate_stats(h);
     const int nb = (int)h->n_blocks;
     {
       ProfScope ps(h, 3);
@@ -3704,7 +3732,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
 // that an all-reduce(sum) over st_mg_top_region() completes them
 extern "C" int st_sample_w_local(st_handle h, const double *z, uint64_t seed, uint32_t iter) {
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
   int rc = gen_or_upload_z(h, z, seed, iter, 0u, h->d_z.p);
   if (rc) return rc;
@@ -3724,7 +3752,7 @@ extern "C" int st_mg_top_region(st_handle h, void **dev_ptr, int64_t *len) {
 }
 extern "C" int st_sample_w_top(st_handle h) {   // the replicated levels above the cut
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
   const int rc = sample_launch(h, std::min(h->cut, h->n_actual_groups), 0);
   if (rc == ST_OK) h->gram_valid = true;   // every record now carries the Gram sums of the accepted theta
@@ -3743,7 +3771,7 @@ extern "C" int st_mg_pack_w(st_handle h, void **dev_ptr, int64_t *len) {
 }
 extern "C" int st_mg_unpack_w(st_handle h) {
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
   double errw[64];
   HCHK(h, hipMemcpyAsync(h->d_w.p, h->d_tmp_n.p, (size_t)h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -3777,7 +3805,7 @@ static int gather_w_scatter(st_handle h) {   // launches only: rows into w, fail
 }
 extern "C" int st_mg_gather_w_unpack(st_handle h) {
   if (!h) return ST_ERR_USAGE;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
   int rc = gather_w_scatter(h);
   if (rc) return rc;
@@ -3876,7 +3904,7 @@ extern "C" int st_predict(st_handle h, int theta_changed) {
   (void)theta_changed;  // H of a prediction block is rebuilt from the ancestor chain every call: same values as the cache
   if (!h) return ST_ERR_USAGE;
   if (h->pred_list.empty()) return ST_OK;
-  h->stats_valid = false; h->host_stats_valid = false;
+  invalidate_stats(h);
   if (!h->z_valid) { h->err = "st_predict needs the normals of a preceding st_sample_w (spamtree_model.cpp:1325)"; return ST_ERR_USAGE; }
   if (h->theta[0].empty()) { h->err = "st_predict before st_factor(slot 0)"; return ST_ERR_USAGE; }
   HCHK(h, hipSetDevice(h->device));
@@ -3900,14 +3928,15 @@ extern "C" int st_predict(st_handle h, int theta_changed) {
   return ST_OK;
 }
 
-static int run_stats(st_handle h) {
+static int run_stats(st_handle h, hipStream_t st = nullptr) {
   const int nq = h->p * h->q + h->q;
   if (h->stats_valid) return ST_OK;   // w and XB unchanged since the last reduction: both statistics are still current
+  if (!st) st = h->stream;
   {
-    ProfScope ps(h, 4);
-    hipLaunchKernelGGL(k_stats, dim3(STATS_WG), dim3(NT), 0, h->stream, h->d_X.p, h->d_y.p, h->d_w.p, h->d_xb.p, h->d_mv.p, h->d_obs.p,
+    ProfScope ps(h, 4, -1, 1, st);
+    hipLaunchKernelGGL(k_stats, dim3(STATS_WG), dim3(NT), 0, st, h->d_X.p, h->d_y.p, h->d_w.p, h->d_xb.p, h->d_mv.p, h->d_obs.p,
                        h->d_partner.p, h->n_all, h->p, h->q, h->d_partial.p);
-    hipLaunchKernelGGL(k_stats_final, dim3(nq), dim3(NT), 0, h->stream, h->d_partial.p, STATS_WG, nq, h->d_stats.p);
+    hipLaunchKernelGGL(k_stats_final, dim3(nq), dim3(NT), 0, st, h->d_partial.p, STATS_WG, nq, h->d_stats.p);
   }
   HCHK(h, hipGetLastError());
   h->stats_valid = true;
@@ -3918,6 +3947,10 @@ static int fetch_stats(st_handle h) {
   if (h->stats_valid && h->host_stats_valid) return ST_OK;
   int rc = run_stats(h);
   if (rc) return rc;
+  if (h->stats_on_stream2) {   // started under phase A (stats_begin): its results before the copy
+    HCHK(h, hipStreamWaitEvent(h->stream, h->ev_stats, 0));
+    h->stats_on_stream2 = false;
+  }
   const size_t nq = (size_t)h->p * h->q + h->q;
   h->host_stats.resize(nq);
   HCHK(h, hipMemcpyAsync(h->host_stats.data(), h->d_stats.p, nq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
