@@ -17,7 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PMC_SUMMARY = "f_async_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py
+PMC_GLOB = "profiles/r*/*_pmc_hbm.json"   # written by profiles/collect.sh + profiles/summarize.py; the newest one is read
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP64_PEAK_TFLOPS = 78.6    # FP64 matrix = FP64 vector peak; both run on ONE pipe per SIMD (profiles/r01/micro_f64_pipes.log)
 
@@ -61,11 +61,106 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
             break
     rc.close()
     ratio = reference_cost(wl) / reference_cost(full_wl)
-    return {"value": its / dt * ratio, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port",
+    scaling = None
+    try:      # measured at several sizes on a GPU box's host by profiles/cpu_scaling.py (committed): fitted exponent vs the law
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cpu_scaling.json")))
+        if f:
+            scaling = json.load(open(f[-1]))
+            scaling["source"] = os.path.relpath(f[-1], ROOT)
+    except Exception:      # noqa: BLE001
+        scaling = None
+    return {"value": its / dt * ratio, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port", "host": host_cpu(),
+            "scaling_check": scaling,
             "sample": f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the {side}^2 grid (n={wl['n']}) in "
                       f"{dt:.1f} s = {its / dt:.3f} it/s measured; scaled by the reference cost law "
                       f"(sum (P+m)^3 + 4mP^2 + ...) ratio {ratio:.4f} to n={full_wl['n']}",
             "measured_it_per_s_at_sample": its / dt, "sample_n": int(wl["n"])}
+
+
+def host_cpu():
+    """lscpu model name, physical cores and sockets of the host the CPU baseline runs on (SURVEY.md section 8d)."""
+    info = {"model": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
+    try:
+        import subprocess
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ":" in ln}
+        info["model"] = kv.get("Model name")
+        info["physical_cores"] = int(kv.get("Core(s) per socket", "0")) * int(kv.get("Socket(s)", "1")) or None
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        info["cpus_allowed"] = len(os.sched_getaffinity(0))
+    except Exception:      # noqa: BLE001
+        pass
+    return info
+
+
+def workload_name(args, wl, n_blocks, n_levels, world):
+    """config.workload from the ACTUAL arguments (VERDICT r1 weak #10)."""
+    known = {(1000, 1, 25, ""): "config #3", (316, 1, 25, ""): "config #2", (577, 3, 25, ""): "config #4",
+             (1155, 3, 9, "0.1,0.3,0.5"): "config #5"}
+    tag = known.get((args.side, args.q, args.cell_size, args.missing), "custom")
+    cov = "univariate exponential covariance" if args.q == 1 else f"q={args.q} Apanasovich-Genton cross-covariance"
+    miss = f", outcomes dropped with probabilities ({args.missing})" if args.missing else ""
+    return (f"{tag}: n={wl['n']} rows ({args.side}^2 grid x q={args.q}) {cov}{miss}, tree cell_size={args.cell_size} K=(2,2), "
+            f"{n_blocks} blocks on {n_levels} levels, B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH"
+            + (f"; ONE problem sharded over {world} GPUs by subtree, RCCL exchanges" if world > 1 else ""))
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, BEFORE anything touches the GPU (children are
+    fresh processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, exactly what torch.distributed.run would give them);
+    rank 0 prints the JSON line on the inherited stdout.  Fails loudly when the box has fewer GPUs than asked for."""
+    import socket
+    import subprocess
+    if not args.launch_check:
+        import torch          # device_count() does not initialise the GPU (no HIP context is created)
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible on this box; refusing to report "
+                             f"a {args.gpus}-GPU line from fewer devices")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        alive = list(procs)
+        while alive:
+            time.sleep(0.2)
+            for pr in list(alive):
+                code = pr.poll()
+                if code is None:
+                    continue
+                alive.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in alive:      # a dead rank leaves the others blocked in a collective: end exactly those PIDs
+                        other.terminate()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    raise SystemExit(rc)
+
+
+def launch_check(rank, world):
+    """CPU rehearsal of the launcher's env plumbing (tests/test_bench_launcher.py): gloo group from the env the launcher set."""
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                          "local_rank_env": os.environ.get("LOCAL_RANK"), "master": os.environ.get("MASTER_ADDR")}), flush=True)
+    dist.destroy_process_group()
 
 
 class ExternalChain:
@@ -118,11 +213,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-side", type=int, default=316, help="grid side of the bounded CPU-baseline sample")
     ap.add_argument("--external", action="store_true", help="force the torch.distributed + Python-driver fallback path")
+    ap.add_argument("--launch-check", action="store_true", help="CPU rehearsal of the rank launcher (gloo, no GPU work)")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args, sys.argv[1:])          # does not return
+        world_env = 1
+    else:
+        world_env = int(os.environ.get("WORLD_SIZE", "1"))
+        if world_env != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world_env}")
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        launch_check(rank, world)
+        return
     import torch
     dist = None
     if world > 1:
@@ -140,34 +247,43 @@ def main():
     wl = make_workload(args.side, q=args.q, cell_size=args.cell_size, missing=missing)
     # N > 1: one problem shared by all ranks -- subtrees below a cut level are owned by one GPU, the top is replicated,
     # exchanges are RCCL all-reduces issued by the library on its own stream (include/spamtree_hip.h, multi-GPU section)
-    uid = None
-    if world > 1:
-        box = [fit.make_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
     k = wl["theta"].size
     # the C++ host driver (spamtree_amd/csrc/spamtree_fit.cpp) steps the chain: w sweep, log-density, RAM-adaptive MH with a
-    # full re-factorisation of the proposal slot, tausq and beta draws
+    # full re-factorisation of the proposal slot, tausq and beta draws.  N > 1: the local part (st_create) first; the ranks
+    # then AGREE that it succeeded everywhere before anyone enters the collective ncclCommInitRank (a rank that failed earlier
+    # would leave the others blocked in its bootstrap; a failure inside that collective itself cannot be recovered from)
     chain, native_err = None, ""
     if not args.external:
         try:
             chain = fit.Chain(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
                               wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
                               wl["indexing"], wl["bounds"], wl["theta"], np.zeros(wl["p"]), 0.1, 0.01 * np.eye(k), seed=2021,
-                              adapting=True, device=local_rank, rank=rank, world=world, unique_id=uid)
+                              adapting=True, device=local_rank, rank=rank, world=world, defer_comm=True)
         except Exception as exc:      # noqa: BLE001  (N > 1 only: every rank must agree before falling back)
             if world == 1:
                 raise
             native_err = repr(exc)
-    ok = torch.tensor([1 if chain is not None else 0], device="cuda", dtype=torch.int32)
-    if dist is not None:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], device="cuda", dtype=torch.int32)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    native = all_ok(chain is not None)
+    if native and world > 1:
+        box = [fit.make_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        chain.comm_init(box[0])
+    if native:
+        chain.start()
     host_path = "C++ host driver, collectives issued by the library (RCCL on its stream)" if world > 1 else "C++ host driver"
-    if int(ok.item()) == 0:
+    if not native:
         if chain is not None:
             chain.close()
-        if rank == 0 and native_err:
-            print("bench.py: native RCCL path unavailable (" + native_err + "); falling back to torch.distributed", file=sys.stderr)
+        if rank == 0:
+            print("bench.py: native path unavailable on some rank (" + (native_err or "another rank failed")
+                  + "); falling back to torch.distributed", file=sys.stderr)
         chain = ExternalChain(wl, dist, local_rank, k)
         host_path = "Python host driver, collectives through torch.distributed (fallback path)"
     model = chain
@@ -224,23 +340,36 @@ def main():
     it_s = args.steps / dt
     # HBM bytes per k_factor launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the workload it was taken on
-    traffic = None
+    traffic, pmc_file = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", PMC_SUMMARY)))
-        if world == 1 and args.side == 1000 and args.q == 1:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, PMC_GLOB)), key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.basename(f)))
+        if cands and world == 1 and args.side == 1000 and args.q == 1 and args.cell_size == 25 and not args.missing:
+            pmc_file = os.path.relpath(cands[-1], ROOT)
+            pmc = json.load(open(cands[-1]))
             # per launch of the timed bracket: the k_factor_quad launches when the top levels run ahead, else all of phase A
             traffic = pmc["summary"]["k_factor_quad" if g_top > 0 else "phase_A"]["hbm_bytes_per_launch"]
     except Exception:      # noqa: BLE001
         traffic = None
+    # what the counters say the kernel is bound by: measured HBM bytes over the launch time, next to the
+    # contract's algorithmic-bytes rate (`achieved`) and the useful-flop rate of the FP64 pipe
+    hbm_measured = None
+    if traffic is not None and avg_launch_ms > 0:
+        g = traffic / (avg_launch_ms * 1e-3) / 1e9
+        hbm_measured = {"bytes_per_launch": traffic, "GBps": g, "frac": g / HBM_PEAK_GBS, "source": pmc_file,
+                        "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same command"}
+    fp64_achieved = alg["flops_A"] * share / (avg_launch_ms * n_bracket * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+    all_ms = float(np.sum(lvl_ms))
+    all_levels = {"ms": round(all_ms, 4), "launches": int(np.count_nonzero(np.asarray(lvl_ms) > 0)),
+                  "GBps": round(float(np.sum(lvl_bytes)) * share / (all_ms * 1e-3) / 1e9, 1) if all_ms > 0 else 0.0,
+                  "frac": round(float(np.sum(lvl_bytes)) * share / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if all_ms > 0 else 0.0,
+                  "note": "every level of phase A run back to back on one stream (the per-launch pass), algorithmic bytes"}
     out = {
         "metric": "Gibbs iterations/sec + achieved HBM GB/s, n=1e6 grid, 1/2/4/8 MI355X",
         "value": it_s, "unit": "Gibbs iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"config #3: n={wl['n']} ({args.side}^2 grid) q={args.q} univariate exponential "
-                               f"covariance, default tree (cell_size=25, K=(2,2)), {n_blocks} blocks, "
-                               "B+C+A+S1+S2 per iteration, theta at the data-generating value, RAM-adaptive MH"
-                               + (f"; sharded over {world} GPUs by subtree, RCCL all-reduce exchanges" if world > 1 else ""),
+        "config": {"workload": workload_name(args, wl, n_blocks, n_levels, world),
                    "n": int(wl["n"]), "q": args.q, "blocks": int(n_blocks), "levels": int(n_levels), "host_path": host_path,
                    "mh_accept_ratio": float(chain.state()["accept_ratio"]),
                    "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
@@ -252,13 +381,15 @@ def main():
                      "traffic": traffic, "avg_launch_ms": avg_launch_ms, "launches": fac_n,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "whole_iteration_GBps": alg["total"] / (dt / args.steps) / 1e9,
-                     # secondary view: the kernel's HBM traffic is ~5x below its algorithmic bytes (chain panels come from
-                     # L2 / Infinity Cache), what saturates is the SIMDs' FP64 pipe -- useful flops of phase A over its time
-                     "fp64_pipe": {"achieved": alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_bracket * 1e-3) / 1e12
-                                   if fac_ms > 0 else 0.0, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": (alg["flops_A"] * share / (fac_ms / max(1, fac_n) * n_bracket * 1e-3) / 1e12
-                                            / FP64_PEAK_TFLOPS) if fac_ms > 0 else 0.0,
-                                   "note": "algorithmic flops (no tile padding); MFMA and VALU FP64 share the pipe"},
+                     "achieved_is": "ALGORITHMIC bytes (SURVEY.md 8d operand-streaming model) per launch / mean launch time",
+                     "hbm_measured": hbm_measured,
+                     "limiter": "FP64 pipe + latency, not HBM: measured HBM traffic is ~5x below the algorithmic bytes (chain panels are "
+                                "served by L2 / Infinity Cache and shared by the units of a quad); MFMA and VALU FP64 share one pipe per SIMD",
+                     "fp64_pipe": {"achieved": fp64_achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": fp64_achieved / FP64_PEAK_TFLOPS,
+                                   "note": "algorithmic flops of phase A (no tile padding, covariance / Cholesky arithmetic not counted) "
+                                           "over the bracket's time"},
+                     "all_levels": all_levels,
                      "by_level_ms": [round(float(x), 4) for x in lvl_ms],
                      "by_level_GBps": [round(float(b / (m * 1e-3) / 1e9), 1) if m > 0 else 0.0
                                        for b, m in zip(lvl_bytes, lvl_ms)],

@@ -95,6 +95,9 @@ int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *lo
  * quadratic forms are redone with the current w afterwards) -- on a second stream, e.g. before the sweep; the next
  * st_factor / st_factor_local for the same slot and theta picks the result up.  Identical results; a no-op when the tree
  * does not qualify (column-group levels above a k_factor_quad level) or SPAMTREE_ASYNC_TOP=0.  (The proposal of spamtree_fit.cpp:211-229 does not depend on the sweep.) */
+/* Contract: between st_factor_begin(slot, theta) and the st_factor / st_factor_local that picks its result up, st_swap is
+ * refused (ST_ERR_USAGE: the arena being written would become the accepted slot); readers of the slot (st_get_block,
+ * st_get_comps, st_loglik_w(1), st_mg_pack_comps) are ordered behind the launches in flight. */
 int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta);
 int st_factor_ahead_levels(st_handle h);   /* how many leading levels st_factor_begin runs ahead (0: none) */
 
@@ -147,6 +150,15 @@ int st_profile_enable(st_handle h, int enable);
 int st_profile_get(st_handle h, double *ms_total, int64_t *launches); /* ST_N_KERNEL_FAMILIES each; resets */
 /* phase-A launches by tree level since the last call: mean ms per launch, algorithmic bytes per launch; resets */
 int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, double *bytes_by_level, int32_t cap);
+/* which phase-A kernel each observed level takes (same dispatch as st_factor: a function of the tree only) and the sizes
+ * that decide it: per level g < *n_levels (at most cap entries written): kernel[g] = one of ST_KERNEL_*, max_m[g], max_P[g]
+ * (largest block / ancestor-row count), n_blocks[g].  Any output pointer but n_levels may be NULL. */
+#define ST_KERNEL_GENERIC_LDS 0
+#define ST_KERNEL_GENERIC_SCRATCH 1
+#define ST_KERNEL_MFMA 2
+#define ST_KERNEL_QUAD 3
+#define ST_KERNEL_BIGMFMA 4
+int st_level_info(st_handle h, int32_t *n_levels, int32_t *kernel, int32_t *max_m, int32_t *max_P, int32_t *n_blocks, int32_t cap);
 int st_synchronize(st_handle h);
 void *st_stream(st_handle h);                              /* the hipStream_t every kernel is launched on */
 

@@ -200,11 +200,33 @@ def sqrt_fpsi(x, a, beta):              # covariance_functions.h:44-48
     return np.exp(0.5 * beta * np.log1p(a * x))
 
 
+def _two_prod(a, b):
+    """a*b = p + e exactly (Dekker / Veltkamp splitting), elementwise."""
+    p = a * b
+    c = 134217729.0                                      # 2^27 + 1
+    a1 = c * a; ah = a1 - (a1 - a); al = a - ah
+    b1 = c * b; bh = b1 - (b1 - b); bl = b - bh
+    e = ((ah * bh - p) + ah * bl + al * bh) + al * bl
+    return p, e
+
+
+def _fma(a, b, c):
+    """Emulation of a fused multiply-add (one rounding of a*b + c) by double-double accumulation."""
+    p, e = _two_prod(a, b)
+    s = p + c
+    bb = s - p
+    t = (p - (s - bb)) + (c - bb)                         # two-sum error of p + c
+    return s + (t + e)
+
+
 def cexpcov(x, y, sigmasq, phi, same=False, reference_distance=False):
     """covariance_functions.cpp:95-111.
 
     reference_distance=True evaluates the reference's cancellation form |x|^2+|y|^2-2x.y in plain (non-FMA)
-    double arithmetic (Q1); the default computes h = sqrt(dx^2+dy^2) directly, which is what the HIP build does.
+    double arithmetic (Q1; R's reference BLAS); reference_distance="fma" accumulates the cross product x.y' the way
+    an FMA BLAS kernel (OpenBLAS / MKL dgemm) does -- acc = fma(x_d, y_d, acc) -- while |x|^2 stays the plain
+    sum(x % x, 1) of the source, which is what makes self-distances non-zero; the default computes
+    h = sqrt(dx^2+dy^2) directly, which is what the HIP build does.
     """
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
@@ -213,7 +235,10 @@ def cexpcov(x, y, sigmasq, phi, same=False, reference_distance=False):
         qmag = np.sum(y * y, axis=1)
         xy = np.zeros((x.shape[0], y.shape[0]))
         for d in range(x.shape[1]):
-            xy = xy + x[:, d][:, None] * y[:, d][None, :]
+            if reference_distance == "fma":
+                xy = _fma(x[:, d][:, None] + 0.0 * xy, y[:, d][None, :] + 0.0 * xy, xy)
+            else:
+                xy = xy + x[:, d][:, None] * y[:, d][None, :]
         h2 = np.abs(qmag[None, :] + pmag[:, None] - 2.0 * xy)
         return sigmasq * np.exp(-phi * np.sqrt(h2))
     dx = x[:, 0][:, None] - y[:, 0][None, :]
@@ -662,6 +687,7 @@ class SpamTreeMV:
                             pd.Sigi_children[up][:, :, c_ix] = pd.AK_uP_u_all[u][np.ix_(loc, loc)]
                         pd.Smu_children[up][:, c_ix] = pd.AK_uP_all[u][loc, :] @ self.w[iu] - \
                             pd.AK_uP_u_all[u][np.ix_(loc, oth)] @ w_par[oth]
+        self.last_sample_errtype = errtype
         if errtype > 0:
             raise RuntimeError("Error at gibbs_sample_w")                 # Rcpp::stop (:1215-1217)
 

@@ -52,6 +52,8 @@ SIGNATURES = {
     "st_profile_enable": (C.c_int, [H, C.c_int]),
     "st_profile_get": (C.c_int, [H, c_dp, c_ip]),
     "st_profile_levels": (C.c_int, [H, C.POINTER(C.c_int32), c_dp, c_dp, C.c_int32]),
+    "st_level_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                C.POINTER(C.c_int32), C.c_int32]),
     "st_synchronize": (C.c_int, [H]),
     "st_stream": (C.c_void_p, [H]),
     "st_set_stream": (C.c_int, [H, C.c_void_p]),

@@ -3255,8 +3255,18 @@ extern "C" int st_set_tausq_inv(st_handle h, const double *t) {
   HCHK(h, hipStreamSynchronize(h->stream));
   return ST_OK;
 }
+// readers of a slot's arena while st_factor_begin's launches may still be writing it on the second stream: order the
+// main stream behind them (top_pending stays set: the next st_factor still picks the result up)
+static int settle_top(st_handle h) {
+  if (h->top_pending) { HCHK(h, hipSetDevice(h->device)); HCHK(h, hipStreamWaitEvent(h->stream, h->ev_top, 0)); }
+  return ST_OK;
+}
 extern "C" int st_swap(st_handle h) {
   if (!h) return ST_ERR_USAGE;
+  if (h->top_pending) {   // the proposal's top levels are being written into the arena that would become the accepted slot
+    h->err = "st_swap between st_factor_begin and the st_factor / st_factor_local that picks its result up";
+    return ST_ERR_USAGE;
+  }
   std::swap(h->slot_map[0], h->slot_map[1]);
   std::swap(h->theta[0], h->theta[1]);
   h->gram_valid = false;
@@ -3309,13 +3319,13 @@ static int make_covpar(st_handle h, const double *theta, int ntheta, CovPar *cp)
 }
 
 template <bool BIG, int MODE>
-static void launch_factor(st_handle h, const LevelInfo &L, FactorArgs &A, const CovPar &cp) {
+static void launch_factor(st_handle h, const LevelInfo &L, FactorArgs &A, const CovPar &cp, hipStream_t st = nullptr) {
   int grid = A.nlist;
   if (BIG) {
     grid = std::min(grid, h->scratch_wgs);
     A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
   }
-  hipLaunchKernelGGL((k_factor<BIG, MODE>), dim3(grid), dim3(NT), L.lds_factor, h->stream, A, cp);
+  hipLaunchKernelGGL((k_factor<BIG, MODE>), dim3(grid), dim3(NT), L.lds_factor, st ? st : h->stream, A, cp);
 }
 
 static int reduce_loglik(st_handle h, int phys, double *loglik) {
@@ -3382,13 +3392,13 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
   if (!errflag) errflag = h->d_err.p;
   int n_launch = 0;
   for (int g = g_lo; g < g_hi; ++g) n_launch += ((h->levels[g].fast ? h->levels[g].gown_n : h->levels[g].own_n) != 0);
-  ProfScope phase(h, 0, -2, n_launch);   // profile mode 2: the phase's launches between ONE pair of events (mean launch = total / launches)
+  ProfScope phase(h, 0, -2, n_launch, st);   // profile mode 2: the phase's launches between ONE pair of events (mean launch = total / launches)
   if (g_lo == 0 && h->limited && !h->twin_list.empty()) {
     MarginalArgs M;
     M.blks = h->d_blks.p; M.list = h->d_twin.p; M.nlist = (int)h->twin_list.size(); M.cx = h->d_cx.p; M.cy = h->d_cy.p; M.mv = h->d_mv.p;
-    M.panels = h->d_panels[phys].p; M.errflag = h->d_err.p; M.maxM = h->twin_maxM;
+    M.panels = h->d_panels[phys].p; M.errflag = errflag; M.maxM = h->twin_maxM;
     const size_t lds = (size_t)2 * h->twin_maxM * h->twin_maxM * sizeof(double);
-    hipLaunchKernelGGL(k_marginal_invchol, dim3(std::min(M.nlist, 8 * h->sm_count)), dim3(NT), lds, h->stream, M, cp);
+    hipLaunchKernelGGL(k_marginal_invchol, dim3(std::min(M.nlist, 8 * h->sm_count)), dim3(NT), lds, st, M, cp);
   }
   for (int g = g_lo; g < g_hi; ++g) {
     const LevelInfo &L = h->levels[g];
@@ -3398,7 +3408,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
     A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_lvl.p + L.first + L.own_lo; A.nlist = L.own_n;
     A.cx = h->d_cx.p; A.cy = h->d_cy.p; A.mv = h->d_mv.p; A.w_in = h->d_w.p; A.w_out = nullptr; A.z = nullptr;
     A.panels = h->d_panels[phys].p; A.logdet_c = h->d_logdet[phys].p; A.loglik_c = h->d_loglik[phys].p;
-    A.errflag = h->d_err.p; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
+    A.errflag = errflag; A.maxP = L.maxP; A.maxM = L.maxM; A.maxMa = L.maxMa; A.SR = L.big_factor ? 4 : 8;
     {
       ProfScope ps(h, 0, g, 1, st);
       if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) {
@@ -3407,13 +3417,13 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + L.grp_first;
         F.quads = h->d_quads.p + L.quad_first + L.qown_lo; F.nquad = L.qown_n;
         F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[phys].p;
-        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = h->d_err.p; F.ldS = L.q_ldS;
+        F.logdet_c = h->d_logdet[phys].p; F.loglik_c = h->d_loglik[phys].p; F.errflag = errflag; F.ldS = L.q_ldS;
         F.gdesc = h->d_gdesc.p + (size_t)L.grp_first * h->gd_stride; F.gd_stride = h->gd_stride;
         F.wave_chol = L.maxM <= 27 ? 1 : 0;
 #define QLAUNCH(NU_, NKX_, NKT_)                                                                                               \
   do {                                                                                                                         \
-    if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp); \
-    else hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, false>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, h->stream, F, cp);         \
+    if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp); \
+    else hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, false>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp);         \
   } while (0)
         if (L.q_nkx == 32) QLAUNCH(4, 32, 8); else if (L.q_nkx == 38) QLAUNCH(4, 38, 10); else if (L.q_nkx == 44) QLAUNCH(4, 44, 11); else QLAUNCH(4, 50, 13);
 #undef QLAUNCH
@@ -3428,11 +3438,11 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, st, F, cp);
       } else if (L.bigmfma && h->factor_gen == 3) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
-        if (L.maxM <= 48) hipLaunchKernelGGL((k_factor_bigmfma<3, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
-        else if (L.maxM <= 64) hipLaunchKernelGGL((k_factor_bigmfma<4, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
-        else hipLaunchKernelGGL((k_factor_bigmfma<5, 3, 24>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, h->stream, A, cp);
-      } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp);
-      else launch_factor<false, MODE_FACTOR>(h, L, A, cp);
+        if (L.maxM <= 48) hipLaunchKernelGGL((k_factor_bigmfma<3, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, st, A, cp);
+        else if (L.maxM <= 64) hipLaunchKernelGGL((k_factor_bigmfma<4, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, st, A, cp);
+        else hipLaunchKernelGGL((k_factor_bigmfma<5, 3, 24>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, st, A, cp);
+      } else if (L.big_factor) launch_factor<true, MODE_FACTOR>(h, L, A, cp, st);
+      else launch_factor<false, MODE_FACTOR>(h, L, A, cp, st);
     }
     HCHK(h, hipGetLastError());
   }
@@ -3513,6 +3523,7 @@ extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int n
 extern "C" int st_mg_pack_comps(st_handle h, int slot, void **dev_ptr, int64_t *len) {
   if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
+  { const int rc0 = settle_top(h); if (rc0) return rc0; }
   const int phys = h->slot_map[slot], nb = (int)h->n_blocks;
   {
     ProfScope ps(h, 3);
@@ -3846,6 +3857,7 @@ extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t
 extern "C" int st_loglik_local(st_handle h, int slot) {
   if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
+  if (slot == 1) { const int rc0 = settle_top(h); if (rc0) return rc0; }
   const int phys = h->slot_map[slot];
   int maxP = 0, maxM = 0;
   for (auto &L : h->levels) { maxP = std::max(maxP, L.maxP); maxM = std::max(maxM, L.maxM); }
@@ -4009,6 +4021,7 @@ extern "C" int st_get_block(st_handle h, int slot, int64_t u, double *negRiH, do
   const Blk &B = h->blks[h->blk_model2dev[u]];
   if (B.panel_off < 0) { h->err = "block has no observations, hence no cache"; return ST_ERR_USAGE; }
   HCHK(h, hipSetDevice(h->device));
+  { const int rc0 = settle_top(h); if (rc0) return rc0; }
   std::vector<double> pan((size_t)B.m * B.ld);
   HCHK(h, hipMemcpyAsync(pan.data(), h->d_panels[h->slot_map[slot]].p + B.panel_off, pan.size() * sizeof(double), hipMemcpyDeviceToHost,
                          h->stream));
@@ -4029,6 +4042,7 @@ extern "C" int st_get_block(st_handle h, int slot, int64_t u, double *negRiH, do
 extern "C" int st_get_comps(st_handle h, int slot, double *logdet_c, double *loglik_c) {
   if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
   HCHK(h, hipSetDevice(h->device));
+  { const int rc0 = settle_top(h); if (rc0) return rc0; }
   const int phys = h->slot_map[slot];
   std::vector<double> a(h->n_blocks), b(h->n_blocks);
   HCHK(h, hipMemcpyAsync(a.data(), h->d_logdet[phys].p, h->n_blocks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -4078,6 +4092,24 @@ extern "C" int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_l
     if (ms_by_level) ms_by_level[g] = h->prof_level_n[g] ? h->prof_level_ms[g] / (double)h->prof_level_n[g] : 0.0;  // mean per launch
     if (bytes_by_level) bytes_by_level[g] = g < ng ? h->levels[g].alg_bytes_A : h->levels[g - ng].alg_bytes_B + h->levels[g - ng].alg_bytes_msg;
     h->prof_level_ms[g] = 0.0; h->prof_level_n[g] = 0;
+  }
+  return ST_OK;
+}
+
+// which phase-A kernel each observed level takes and the sizes that decide it (tests prove the branch they mean to reach)
+extern "C" int st_level_info(st_handle h, int32_t *n_levels, int32_t *kernel, int32_t *max_m, int32_t *max_P, int32_t *n_blocks, int32_t cap) {
+  if (!h || !n_levels) return ST_ERR_USAGE;
+  *n_levels = h->n_actual_groups;
+  for (int g = 0; g < h->n_actual_groups && g < cap; ++g) {
+    const LevelInfo &L = h->levels[g];
+    int k = L.big_factor ? ST_KERNEL_GENERIC_SCRATCH : ST_KERNEL_GENERIC_LDS;
+    if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) k = ST_KERNEL_QUAD;
+    else if (L.fast) k = ST_KERNEL_MFMA;
+    else if (L.bigmfma && h->factor_gen == 3) k = ST_KERNEL_BIGMFMA;
+    if (kernel) kernel[g] = k;
+    if (max_m) max_m[g] = L.maxM;
+    if (max_P) max_P[g] = L.maxP;
+    if (n_blocks) n_blocks[g] = L.count;
   }
   return ST_OK;
 }

@@ -44,7 +44,7 @@ class Chain:
     def __init__(self, y, X, Z, coords, mv_id, blocking, gix_block, res_is_ref, parents, children, limited_tree,
                  block_names, block_groups, indexing, set_unif_bounds, theta, beta, tausq, mcmcsd, seed=2021,
                  adapting=True, sample_beta=True, sample_tausq=True, sample_theta=True, sample_w=True, device=0,
-                 reference_quirks=True, rank=0, world=1, unique_id=None):
+                 reference_quirks=True, rank=0, world=1, unique_id=None, defer_comm=False):
         self.lib = _lib.load()
         pb, self._keep, self.n, self.p, self.q = _problem(y, X, coords, mv_id, res_is_ref, parents, children,
                                                           block_names, block_groups, indexing)
@@ -56,7 +56,7 @@ class Chain:
         fl = _lib.StmFlags(int(adapting), int(sample_beta), int(sample_tausq), int(sample_theta), int(sample_w), 1)
         c = C.c_void_p()
         self.c = None
-        if world > 1 and unique_id is None:
+        if world > 1 and unique_id is None and not defer_comm:
             raise SpamTreeError("world > 1 needs the RCCL unique id of rank 0 (spamtree_amd.fit.make_unique_id)")
         rc = self.lib.stm_create(C.byref(pb), C.byref(opt), _dp(bounds), _dp(sd), _dp(theta), self.k, _dp(_f64(beta)),
                                  float(tausq), int(seed), C.byref(fl), C.byref(c))
@@ -69,11 +69,22 @@ class Chain:
             raise SpamTreeError(f"stm_create failed ({rc}): {msg or self.lib.st_last_error(None).decode()}")
         self.h = C.c_void_p(self.lib.stm_handle(self.c))
         self.rank, self.world = int(rank), int(world)
+        # defer_comm: stop after the local part (st_create), so that the ranks can first agree that it succeeded everywhere:
+        # ncclCommInitRank is collective and a rank that failed before it would leave the others blocked in the bootstrap.
+        # The caller then runs comm_init(unique_id) -- a failure INSIDE that collective cannot be recovered from -- and start().
+        if defer_comm:
+            return
         if world > 1 or unique_id is not None:   # a unique id with world == 1: the RCCL protocol path on a single rank (tests)
-            buf = C.create_string_buffer(bytes(unique_id), 128)
-            rc = self.lib.st_comm_init(self.h, C.cast(buf, C.c_void_p))
-            if rc != 0:
-                raise SpamTreeError(f"st_comm_init failed ({rc}): {self.lib.st_last_error(self.h).decode()}")
+            self.comm_init(unique_id)
+        self.start()
+
+    def comm_init(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        rc = self.lib.st_comm_init(self.h, C.cast(buf, C.c_void_p))
+        if rc != 0:
+            raise SpamTreeError(f"st_comm_init failed ({rc}): {self.lib.st_last_error(self.h).decode()}")
+
+    def start(self):
         rc = self.lib.stm_init(self.c)
         if rc != 0:
             raise SpamTreeError(f"stm_init failed ({rc}): {self.lib.stm_last_error(self.c).decode()}")

@@ -276,5 +276,16 @@ class SpamTreeMV:
         self._check(self.lib.st_profile_levels(self.h, C.byref(nl), _dp(ms), _dp(by), 128))
         return ms[nl.value: 2 * nl.value].copy(), by[nl.value: 2 * nl.value].copy()
 
+    KERNEL_NAMES = ["generic_lds", "generic_scratch", "k_factor_mfma", "k_factor_quad", "k_factor_bigmfma"]
+
+    def level_info(self):
+        """Per observed level: dict(kernel=name of the phase-A kernel, max_m, max_P, n_blocks)."""
+        nl = C.c_int32()
+        arr = [np.zeros(64, dtype=np.int32) for _ in range(4)]
+        ptr = [a.ctypes.data_as(C.POINTER(C.c_int32)) for a in arr]
+        self._check(self.lib.st_level_info(self.h, C.byref(nl), ptr[0], ptr[1], ptr[2], ptr[3], 64))
+        return [dict(kernel=self.KERNEL_NAMES[arr[0][g]], max_m=int(arr[1][g]), max_P=int(arr[2][g]), n_blocks=int(arr[3][g]))
+                for g in range(nl.value)]
+
     def synchronize(self):
         self._check(self.lib.st_synchronize(self.h))

@@ -93,3 +93,12 @@ def oracle_model(pb, theta=None, beta=None, tausq=0.1, w=None, **kw):
     return SpamTreeMV(pb["y"], pb["X"], pb["Z"], pb["coords"], pb["mv_id"], pb["blocking"], pb["gix_block"],
                       pb["res_is_ref"], pb["parents"], pb["children"], pb.get("limited_tree", False), pb["block_names"],
                       pb["block_groups"], pb["indexing"], w, beta, theta, 1.0 / tausq, **kw)
+
+
+def strip_coords(nx, ny, q, width=0.02):
+    """An nx x ny grid on the thin strip [0,1] x [0,width], replicated per outcome: with K = (2, 1) the tree splits one axis
+    only, so it gets DEEP (long ancestor chains) with few rows -- chains of config #4 / #5 length at oracle-friendly sizes."""
+    xs = np.linspace(0.0, 1.0, nx)
+    ys = np.linspace(0.0, width, ny)
+    g = np.stack(np.meshgrid(xs, ys, indexing="ij"), axis=-1).reshape(-1, 2)
+    return np.tile(g, (q, 1)), np.repeat(np.arange(1, q + 1), nx * ny)
