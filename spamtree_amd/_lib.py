@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspamtree_hip.so")
+# SPAMTREE_LIB: an alternative build of the SAME library (A/B timing of kernel variants under profiles/micro); never a fallback
+LIB_PATH = os.environ.get("SPAMTREE_LIB") or os.path.join(HERE, "libspamtree_hip.so")
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int64)

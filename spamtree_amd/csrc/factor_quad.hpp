@@ -3,8 +3,11 @@
 // A workgroup factorises up to NU "units" at once.  A unit is what k_factor_mfma calls a column group: one reference
 // block, or up to 32 columns of sibling non-reference blocks.  The units of a quad share their ancestor chain, except
 // possibly for the last ancestor ("private" ancestor: leaf groups whose parents are siblings).  The shared chain's
-// inverse-Cholesky panels are staged through LDS ONCE for all units: whole panels (<= 32 rows) by LDS-DMA into two
-// buffers, the next panel in flight while the matrix cores work on the current one, one LDS-only barrier per panel;
+// inverse-Cholesky panels are staged through LDS ONCE for all units: 32 consecutive ROWS OF THE CONCATENATED CHAIN at a
+// time (the chain's inverse Cholesky factor is one lower-triangular Pc x Pc matrix kept as one row panel per ancestor, so a
+// step may straddle two ancestors: its rows then have different lengths and the shorter ones are zero-filled -- 175 chain
+// rows are 11 row tiles of 16 instead of the 14 that 7 separately padded 25-row panels make) by LDS-DMA into two
+// buffers, the next step in flight while the matrix cores work on the current one, one LDS-only barrier per step;
 // per panel every wave has 4x the matrix work of k_factor_mfma between barriers and nothing is exchanged between the
 // waves of the main loop (the private ancestors' panels: all units side by side, 16 rows at a time, before it):
 //   * wave (u, jt) owns 16 columns of unit u over the WHOLE chain: its K_{pa,u} B operands live in registers (kx),
@@ -44,6 +47,15 @@ struct QuadArgs {
 
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 
+// Row stride (doubles) of the staged chain rows, a function of the instantiation only, so that every LDS operand address
+// of the main loop is ONE per-lane base register + an immediate offset: >= the longest chain (4 NKX) + 24 zero-filled
+// columns, >= 178 (the epilogue's per-unit overlay: Ri, R, T hand-over slots), and 2 x odd (conflict-free A-operand reads).
+__host__ __device__ constexpr int quad_lds_stride(int nkx) {
+  int s = 4 * nkx + 24 > 178 ? 4 * nkx + 24 : 178;
+  while ((s & 1) || ((s >> 1) & 1) == 0) ++s;
+  return s;
+}
+
 // One row of Kb doubles, global -> LDS, by LDS-DMA (16 bytes per lane, 1 KiB per wave-instruction, no registers): lane l
 // moves doubles 2l, 2l+1 of each 128-double piece.  The source needs 8-byte alignment only.  When Kb is odd the last
 // active lane also drops the row's successor into column Kb: the caller zero-fills [Kb, Kb+24) after the data has landed.
@@ -57,7 +69,10 @@ __device__ __forceinline__ void dma_row(const double *src, double *dst, int Kb, 
   }
 }
 
-template <int NU, int NKX, int NKT, bool ISREF>
+// WCH (reference levels): the level's blocks have <= 27 rows -> one-wave register elimination; else the team elimination.
+// A template parameter, not a run-time branch: with both bodies in one kernel the register allocator budgets for the larger
+// one and parks a T accumulator in scratch for the whole main loop.
+template <int NU, int NKX, int NKT, bool ISREF, bool WCH = true>
 __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar cp) {
   constexpr int NTQ = 128 * NU, NW = 2 * NU;
   constexpr int PMAX = 4 * NKX, KH = (NKX + 1) / 2;   // K-steps evaluated per pass through the arena
@@ -74,18 +89,18 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ double s_px[NUL][32], s_py[NUL][32], s_pw[NUL][32];
   __shared__ double s_e2[NU][32], s_lg[NU][32];
   __shared__ int s_colmv[NU][32], s_colblk[NUL][32], s_pmv[NUL][32];
-  struct SubIt { int geo, Kb, pend, pad; long long src, pad2; };   // one staged panel of the shared chain: geo = rows
-  __shared__ SubIt s_it[MAXJ];
-  __shared__ int s_nit;
+  __shared__ int s_nit;   // steps of 32 chain rows over the shared chain
   __shared__ double s_sx[PMAX], s_sy[PMAX], s_wpa[PMAX];
   __shared__ int s_smv[PMAX];
+  __shared__ int s_rlen[PMAX];          // chain row c: its length (entries up to and including its own ancestor's rows) ...
+  __shared__ long long s_rsrc[PMAX];    // ... and where it starts in the panel arena
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, ttid = tid & 127;
   const int wid = RFL(tid >> 6), u = wid >> 1, jt = (wid & 1) ^ ((wid >> 2) & 1);   // waves w, w + 4 share a SIMD: one jt = 0 (it also has the off-diagonal Schur tile) and one jt = 1 each
-  const int ldS = A.ldS;
+  constexpr int ldS = quad_lds_stride(NKX);   // == A.ldS (host)
   double *arena = lds;
   double *zrow = arena + (size_t)NU * 16 * ldS;   // a row of zeros
-  double *xch = zrow + ldS;                       // reference quads only: V tiles of the jt = 1 waves, [2][NU][256]
+  double *xch = zrow + ldS;                       // reference quads only: V tiles of the jt = 1 waves, [NU][2 tiles][256]
 
   STAMP_DECL
   int qidx = blockIdx.x;
@@ -132,16 +147,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   }
   if (tid == 32) {
     s_ao[Jc] = Pc;
-    // the staged panels of the shared chain in processing order (last ancestor first)
-    int n = 0;
-    for (int t = Jc - 1; t >= 0; --t) {
-      const long long *a = gdl + 8 + 4 * t;
-      const int ma = (int)(a[0] & 0xffffffffLL), oa = (int)(a[0] >> 32);
-      SubIt it;
-      it.geo = ma; it.Kb = oa + ma; it.pend = 0; it.pad = 0; it.src = a[2]; it.pad2 = 0;
-      s_it[n++] = it;
-    }
-    s_nit = n;
+    s_nit = (Pc + 31) >> 5;
   }
   for (int e = tid; e < NU * NB; e += NTQ) {
     const int uu = e / NB, b = e - uu * NB;
@@ -171,6 +177,8 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     while (t + 1 < Jc && k >= s_ao[t + 1]) ++t;
     const long long r = s_arow[t] + (k - s_ao[t]);
     s_sx[k] = A.cx[r]; s_sy[k] = A.cy[r]; s_smv[k] = A.mv[r]; s_wpa[k] = A.w[r];
+    const int len = s_ao[t + 1];
+    s_rlen[k] = len; s_rsrc[k] = s_apan[t] + (long long)(k - s_ao[t]) * len;
   }
   for (int e = tid; e < NU * 32; e += NTQ) {
     const int uu = e >> 5, i = e & 31;
@@ -253,97 +261,66 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   d4 tacc[NKT];
 #pragma unroll
   for (int n = 0; n < NKT; ++n) tacc[n] = (d4){0.0, 0.0, 0.0, 0.0};
-  d4 rown = (d4){0.0, 0.0, 0.0, 0.0}, rcross = rown, vprevA = rown, vprevB = rown;   // Schur tiles (jt, jt), (1, 0); previous V tiles
-  double dacc = 0.0;                                               // leaf units: sum_k V[k][column l15]^2 (this lane's rows)
-  int par = 0;
-  bool have_prev = false, prev_wide = false;
+  d4 rown = (d4){0.0, 0.0, 0.0, 0.0}, rcross = rown;   // Schur tiles (jt, jt), (1, 0)
+  double dacc = 0.0;                                   // leaf units: sum_k V[k][column l15]^2 (this lane's rows)
 
 #define QMFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0)
-  // the partner wave's V tiles of the previous panel (LDS) against this wave's: Schur tile (1, 0)
-  auto cross_schur = [&]() {
-    const double *xp = xch + ((par ^ 1) * NU + u) * 512 + lane;
-    const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
-    QMFMA(q0, vprevA[0], rcross); QMFMA(q1, vprevA[1], rcross); QMFMA(q2, vprevA[2], rcross); QMFMA(q3, vprevA[3], rcross);
-    if (prev_wide) {
-      const double q4 = xp[256], q5 = xp[320], q6 = xp[384], q7 = xp[448];
-      QMFMA(q4, vprevB[0], rcross); QMFMA(q5, vprevB[1], rcross); QMFMA(q6, vprevB[2], rcross); QMFMA(q7, vprevB[3], rcross);
-    }
-  };
-  // one panel (sr <= 32 rows of Linv, row length Kb, staged at stg with stride ldS, columns [Kb, Kb+24) zero)
-  auto compute = [&](const double *stg, int sr, int Kb) {
-    if (isref && jt == 0 && two && have_prev) cross_schur();
-    const bool wide = sr > 16;
-    // V = Linv[:, 0:Kb] K[0:Kb, own columns]: tile A = rows 0..15, tile B = rows 16..31 (two independent chains).
-    // One loop nest for both panel heights (two separate bodies made the register allocator spill).
-    const int ns = (Kb + 3) >> 2;
-    d4 pA = (d4){0.0, 0.0, 0.0, 0.0}, pB = pA;
-    {
-      const double *apA = ((l15 < sr) ? stg + (size_t)l15 * ldS : zrow) + l4;
-      const double *apB = ((16 + l15 < sr) ? stg + (size_t)(16 + l15) * ldS : zrow) + l4;
+  // One 16-row tile of the step (rows at tg, nk = ceil(rows / 4) K-steps of the T update, row length KbT): V = Linv K for
+  // the wave's columns, the off-diagonal Schur tile, then T += V' Linv and the diagonal Schur tile, with ONE V accumulator
+  // live at a time (two tiles side by side made the register allocator keep a T accumulator in scratch: its reloads wait on
+  // vmcnt, i.e. on the LDS-DMA of the next step too).  Reference units: the jt = 1 wave hands its V tile to its partner
+  // through LDS slot `slot` of the unit (one workgroup barrier -- every wave takes it, with or without columns), and the
+  // jt = 0 wave forms the Schur tile (1, 0) = V_1' V_0 from it and its own tile, still in registers.
+  auto tile = [&](const double *tg, int nk, int KbT, int slot) __attribute__((always_inline)) {
+    d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+    if (wact) {
+      const int ns = (KbT + 3) >> 2;
+      const double *ap = tg + l15 * ldS + l4;   // rows beyond the step's last are zero (staging)
 #pragma unroll
       for (int c = 0; c < (NKX + 3) / 4; ++c) {
-        if (4 * c < ns) {
-          double a[4], b[4];
+        if (4 * c >= ns) break;   // early exit (not a guarded body): one scalar compare per group, no predicate kept live
+        double a[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) a[i] = apA[4 * (4 * c + i)];
-          if (wide) {
+        for (int i = 0; i < 4; ++i) a[i] = ap[4 * (4 * c + i)];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = apB[4 * (4 * c + i)];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (4 * c + i < NKX) QMFMA(a[i], kx[4 * c + i], pA);
-          if (wide) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (4 * c + i < NKX) QMFMA(b[i], kx[4 * c + i], pB);
-          }
-        }
+        for (int i = 0; i < 4; ++i)
+          if (4 * c + i < NKX) QMFMA(a[i], kx[4 * c + i], p);
       }
     }
-    // T[column][chain k] += V' Linv: A = V tiles (C layout read as A: contraction over the panel rows), B from LDS
-    {
-      const int nst = (sr + 3) >> 2;
-      const double *b0 = ((l4 < sr) ? stg + (size_t)l4 * ldS : zrow) + l15;
-      const double *b1 = ((4 + l4 < sr) ? stg + (size_t)(4 + l4) * ldS : zrow) + l15;
-      const double *b2 = ((8 + l4 < sr) ? stg + (size_t)(8 + l4) * ldS : zrow) + l15;
-      const double *b3 = ((12 + l4 < sr) ? stg + (size_t)(12 + l4) * ldS : zrow) + l15;
-      const double *b4 = ((16 + l4 < sr) ? stg + (size_t)(16 + l4) * ldS : zrow) + l15;
-      const double *b5 = ((20 + l4 < sr) ? stg + (size_t)(20 + l4) * ldS : zrow) + l15;
-      const double *b6 = ((24 + l4 < sr) ? stg + (size_t)(24 + l4) * ldS : zrow) + l15;
-      const double *b7 = ((28 + l4 < sr) ? stg + (size_t)(28 + l4) * ldS : zrow) + l15;
+    if constexpr (ISREF) {
+      double *xp = xch + (u * 2 + slot) * 256 + lane;
+      if (jt == 1 && wact) { xp[0] = p[0]; xp[64] = p[1]; xp[128] = p[2]; xp[192] = p[3]; }
+      lds_barrier();
+      if (jt == 0 && two) {
+        const double q0 = xp[0], q1 = xp[64], q2 = xp[128], q3 = xp[192];
+        QMFMA(q0, p[0], rcross); QMFMA(q1, p[1], rcross); QMFMA(q2, p[2], rcross); QMFMA(q3, p[3], rcross);
+      }
+    }
+    if (wact) {
+      // T[column][chain k] += V' Linv: A = the V tile (C layout read as A: contraction over the tile's rows), B from LDS
+      const double *b0 = tg + l4 * ldS + l15;
 #pragma unroll
       for (int n = 0; n < NKT; ++n) {
-        if (n * 16 < Kb) {
-          const double x0 = b0[16 * n], x1 = b1[16 * n], x2 = b2[16 * n], x3 = b3[16 * n];
-          QMFMA(pA[0], x0, tacc[n]);
-          if (nst > 1) QMFMA(pA[1], x1, tacc[n]);
-          if (nst > 2) QMFMA(pA[2], x2, tacc[n]);
-          if (nst > 3) QMFMA(pA[3], x3, tacc[n]);
-          if (wide) {
-            const double x4 = b4[16 * n], x5 = b5[16 * n], x6 = b6[16 * n], x7 = b7[16 * n];
-            QMFMA(pB[0], x4, tacc[n]);
-            if (nst > 5) QMFMA(pB[1], x5, tacc[n]);
-            if (nst > 6) QMFMA(pB[2], x6, tacc[n]);
-            if (nst > 7) QMFMA(pB[3], x7, tacc[n]);
-          }
-        }
+        if (n * 16 >= KbT) break;
+        const double x0 = b0[16 * n], x1 = b0[4 * ldS + 16 * n], x2 = b0[8 * ldS + 16 * n], x3 = b0[12 * ldS + 16 * n];
+        QMFMA(p[0], x0, tacc[n]);
+        if (nk > 1) QMFMA(p[1], x1, tacc[n]);
+        if (nk > 2) QMFMA(p[2], x2, tacc[n]);
+        if (nk > 3) QMFMA(p[3], x3, tacc[n]);
+      }
+      if (isref) {
+        QMFMA(p[0], p[0], rown); QMFMA(p[1], p[1], rown); QMFMA(p[2], p[2], rown); QMFMA(p[3], p[3], rown);
+      } else {
+        dacc += p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
       }
     }
-    if (isref) {
-      QMFMA(pA[0], pA[0], rown); QMFMA(pA[1], pA[1], rown); QMFMA(pA[2], pA[2], rown); QMFMA(pA[3], pA[3], rown);
-      if (wide) { QMFMA(pB[0], pB[0], rown); QMFMA(pB[1], pB[1], rown); QMFMA(pB[2], pB[2], rown); QMFMA(pB[3], pB[3], rown); }
-      if (jt == 1) {
-        double *xp = xch + (par * NU + u) * 512 + lane;
-        xp[0] = pA[0]; xp[64] = pA[1]; xp[128] = pA[2]; xp[192] = pA[3];
-        if (wide) { xp[256] = pB[0]; xp[320] = pB[1]; xp[384] = pB[2]; xp[448] = pB[3]; }
-      } else { vprevA = pA; vprevB = pB; }
-      have_prev = true; prev_wide = wide;
-      par ^= 1;
-    } else {
-      dacc += pA[0] * pA[0] + pA[1] * pA[1] + pA[2] * pA[2] + pA[3] * pA[3];
-      if (wide) dacc += pB[0] * pB[0] + pB[1] * pB[1] + pB[2] * pB[2] + pB[3] * pB[3];
-    }
+  };
+  // one step (sr <= 32 rows of Linv staged at stg with stride ldS; Kb / KbA: length of the longest row of the step / of its
+  // first tile -- shorter when the step straddles ancestors; columns up to Kb + 24 are zero beyond a row's own length).
+  // Called by every wave of the workgroup (barriers inside for reference units); sr is the same for all of them.
+  auto compute = [&](const double *stg, int sr, int Kb, int KbA) __attribute__((always_inline)) {
+    tile(stg, (min(sr, 16) + 3) >> 2, KbA, 0);
+    if (sr > 16) tile(stg + 16 * ldS, (sr - 16 + 3) >> 2, Kb, 1);
   };
 
   // ---- private (last) ancestors: every unit's sub-panel staged side by side (LDS-DMA), all waves busy
@@ -367,52 +344,64 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
         for (int rr = 0; rr < 8; ++rr) {
           const int row = jt + 2 * rr;
           if (row < sr && lane < 24) buf[(size_t)row * ldS + p_Kb + lane] = 0.0;
+          if (row >= sr) for (int k = lane; k < p_Kb + 24; k += 64) buf[(size_t)row * ldS + k] = 0.0;   // absent rows of the tile
         }
         lds_barrier();
-        if (wact && sr > 0) compute(buf, sr, p_Kb);
+        if (sr > 0) compute(buf, sr, p_Kb, p_Kb);
         lds_barrier();
       }
     }
   }
 
   STAMP(2);
-  // ---- the shared chain, last ancestor first, one whole panel (<= 32 rows) per step.  Panels travel from global memory
-  // straight into one of two LDS buffers (LDS-DMA, no registers): the next one is requested when the matrix cores start
-  // on the current one; one LDS-only barrier per panel.
+  // ---- the shared chain, last rows first, 32 rows of the concatenated chain per step (two 16-row MFMA tiles; the step
+  // that holds the chain's first rows may be shorter).  Rows travel from global memory straight into one of two LDS
+  // buffers (LDS-DMA, no registers): the next step is requested when the matrix cores start on the current one; one
+  // LDS-only barrier per step.  Row c of the chain belongs to ancestor t (s_ao[t] <= c < s_ao[t+1]) and has s_ao[t+1]
+  // entries; a step's row length Kb is that of its last row, shorter rows are zero-filled up to Kb + 24.
   {
     constexpr int RP = 32 / NW;   // rows per wave
     const int nit = RFL(s_nit);
-    auto issue = [&](int i, double *buf) {
-      const SubIt it = s_it[i];
-      const int sr = RFL(it.geo), Kb = RFL(it.Kb);
-      const double *base = A.panels + it.src;
+    auto issue = [&](int i, double *buf) {   // step i covers chain rows [32 (nit-1-i), ...)
+      const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
 #pragma unroll
       for (int rr = 0; rr < RP; ++rr) {
         const int row = wid + NW * rr;
-        if (row < sr) dma_row(base + (size_t)row * Kb, buf + (size_t)row * ldS, Kb, lane, true);
+        if (row < sr) {
+          const int len = RFL(s_rlen[c0 + row]);
+          dma_row(A.panels + s_rsrc[c0 + row], buf + (size_t)row * ldS, len, lane, len > 128);
+        }
       }
     };
     if (nit > 0) issue(0, arena);
     int cur = 0;
     for (int i = 0; i < nit; ++i) {
-      const int sr = RFL(s_it[i].geo), Kb = RFL(s_it[i].Kb);
+      const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
+      const int Kb = RFL(s_rlen[c0 + sr - 1]);
       double *buf = arena + (size_t)cur * 32 * ldS;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current panel have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current step have landed
 #pragma unroll
-      for (int rr = 0; rr < RP; ++rr)
-        if (lane < 24) buf[(size_t)(wid + NW * rr) * ldS + Kb + lane] = 0.0;   // also wipes the DMA's odd-Kb overshoot
+      for (int rr = 0; rr < RP; ++rr) {
+        const int row = wid + NW * rr;
+        if (row < sr) {
+          const int len = RFL(s_rlen[c0 + row]);
+          // zero from the row's own end (this also wipes the DMA's odd-length overshoot) to the step's Kb + 24
+          if (len + lane < Kb + 24) buf[(size_t)row * ldS + len + lane] = 0.0;   // Kb - len <= 32 (blocks of a quad level)
+        } else if (row < (sr > 16 ? 32 : 16)) {
+          for (int k = lane; k < Kb + 24; k += 64) buf[(size_t)row * ldS + k] = 0.0;   // absent rows of a tile in use (first step only)
+        }
+      }
       STAMP(5);
       lds_barrier();
       STAMP(3);
       if (i + 1 < nit) issue(i + 1, arena + (size_t)(cur ^ 1) * 32 * ldS);
       STAMP(6);
-      if (wact) compute(buf, sr, Kb);
+      compute(buf, sr, Kb, RFL(s_rlen[c0 + min(sr, 16) - 1]));
       STAMP(4);
       cur ^= 1;
     }
   }
   lds_barrier();
-  if (isref && jt == 0 && two && have_prev) cross_schur();   // the last panel's off-diagonal Schur update
 
   // ---- hv = T w_pa for this wave's columns (tile rows l4 + 4 r), summed over the 16 chain columns of a tile row
   double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;
@@ -493,7 +482,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   STAMP(11);
   if constexpr (ISREF) {
     // element slots per thread: m (m + 1) <= 128 * slots.  
-    if (A.wave_chol) {
+    if constexpr (WCH) {
       // one wave per unit, registers only (the jt = 0 waves sit on four different SIMDs, which the elimination keeps busy:
       // splitting the columns of L^{-1} over the unit's two waves would put two such waves on every SIMD)
       lds_barrier();   // R complete (both waves of the unit wrote parts of it)

@@ -2923,10 +2923,9 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       L.qown_lo = qlo < qhi ? qlo : 0; L.qown_n = qlo < qhi ? qhi - qlo : 0;
       const int need = (L.maxP + 3) / 4;
       L.q_nkx = need <= 32 ? 32 : (need <= 38 ? 38 : (need <= 44 ? 44 : 50));
-      int ldS = std::max(std::max(L.maxP + 24, 4 * L.q_nkx + 4), 178);
-      while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
+      const int ldS = quad_lds_stride(L.q_nkx);   // the kernel's compile-time row stride (>= maxP + 24)
       L.q_ldS = ldS;
-      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)2 * h->quad_nu * 512 : 0)) * 8;
+      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)h->quad_nu * 512 : 0)) * 8;
       int min_groups = 2 * h->sm_count;   // smaller levels do not fill the chip with quads: k_factor_mfma's 4x more workgroups win
       { const char *e = getenv("SPAMTREE_QUAD_MIN"); if (e) min_groups = atoi(e); }
       if (L.grp_count < 2 * nq_any || mixed || L.grp_count < min_groups) L.q_nkx = 0;   // mostly singletons: nothing to share
@@ -3148,21 +3147,24 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   }
   {
     // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
-    const void *fq = (const void *)k_factor_quad<4, 50, 13, false>;
+    const void *fq = (const void *)k_factor_quad<4, 50, 13, false, true>;
     hipFuncAttributes fa;
     size_t stat = 24 * 1024;
     if (hipFuncGetAttributes(&fa, fq) == hipSuccess) stat = fa.sharedSizeBytes;
     {
-      const void *fr = (const void *)k_factor_quad<4, 50, 13, true>;
+      const void *fr = (const void *)k_factor_quad<4, 50, 13, true, true>;
       if (hipFuncGetAttributes(&fa, fr) == hipSuccess) stat = std::max(stat, (size_t)fa.sharedSizeBytes);
+      const void *ft = (const void *)k_factor_quad<4, 50, 13, true, false>;
+      if (hipFuncGetAttributes(&fa, ft) == hipSuccess) stat = std::max(stat, (size_t)fa.sharedSizeBytes);
     }
     for (auto &L : h->levels) {
       if (L.q_nkx == 0) continue;
       if (L.lds_quad + stat > 160 * 1024) L.q_nkx = 0;
     }
 #define QATTR(NU_, NKX_, NKT_)                                                                                                       \
-  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
-  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat)
+  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
+  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
+  (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat)
     QATTR(4, 50, 13); QATTR(4, 44, 11); QATTR(4, 38, 10); QATTR(4, 32, 8);
 #undef QATTR
   }
@@ -3422,8 +3424,9 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         F.wave_chol = L.maxM <= 27 ? 1 : 0;
 #define QLAUNCH(NU_, NKX_, NKT_)                                                                                               \
   do {                                                                                                                         \
-    if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp); \
-    else hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, false>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp);         \
+    if (L.isref && F.wave_chol) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp); \
+    else if (L.isref) hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, true, false>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp); \
+    else hipLaunchKernelGGL((k_factor_quad<NU_, NKX_, NKT_, false, true>), dim3(L.qown_n), dim3(128 * NU_), L.lds_quad, st, F, cp);         \
   } while (0)
         if (L.q_nkx == 32) QLAUNCH(4, 32, 8); else if (L.q_nkx == 38) QLAUNCH(4, 38, 10); else if (L.q_nkx == 44) QLAUNCH(4, 44, 11); else QLAUNCH(4, 50, 13);
 #undef QLAUNCH
