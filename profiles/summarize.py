@@ -1,5 +1,5 @@
 """Condenses the raw rocprofv3 output of profiles/collect.sh (gpurun_out/<tag>_*) into the committed summaries
-profiles/r01/<tag>_bench.json, <tag>_kernel_stats.csv and <tag>_pmc_hbm.json.
+profiles/<round>/<tag>_bench.json (ROUND env, default r02), <tag>_kernel_stats.csv and <tag>_pmc_hbm.json.
 
 HBM bytes per kernel family = FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md: 128-byte requests are
 tallied at 64 bytes) + WRITE_SIZE, both reported by rocprofv3 in KB, from separate counter passes."""
@@ -14,7 +14,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "c_quad"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out")
-dst = os.path.join(root, "profiles", "r01")
+dst = os.path.join(root, "profiles", os.environ.get("ROUND", "r02"))
 os.makedirs(dst, exist_ok=True)
 
 
@@ -61,3 +61,36 @@ if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
 out["summary"] = summ
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1))
+
+# ---- SQ counter pass (collect.sh, own --pmc run): per kernel INSTANTIATION (the quad kernel's template arguments tell the
+# levels apart), means per launch; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs)
+fs = sorted(glob.glob(os.path.join(src, f"{tag}_pmc_SQ", "*", "*counter_collection.csv")), key=os.path.getmtime)
+if fs:
+    import re
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(dict)
+    for r in csv.DictReader(open(fs[-1])):
+        name = r["Kernel_Name"]
+        m = re.match(r"void (k_\w+)(<[^>]*>)?", name)
+        key = (m.group(1) + (m.group(2) or "")) if m else name[:48]
+        acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        dur[key][r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    sq = {}
+    for key, cs in acc.items():
+        if not key.startswith("k_"):
+            continue
+        d = {c: sum(v) / len(v) for c, v in cs.items()}
+        ms = sum(dur[key].values()) / max(1, len(dur[key]))
+        e = {"launches": len(dur[key]), "mean_ms_under_pmc": round(ms, 4)}
+        e.update({c: round(v, 1) for c, v in d.items()})
+        wc = d.get("SQ_WAVE_CYCLES", 0.0)
+        if ms > 0:
+            e["mfma_busy_frac"] = round(d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (ms * 1e-3 * 2.4e9 * 1024), 3)
+        if wc > 0:
+            e["wave_parked_frac"] = round(d.get("SQ_WAIT_ANY", 0.0) / wc, 3)
+            e["wave_issue_stalled_frac"] = round(d.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)
+            e["wave_issuing_frac"] = round(d.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3)
+        sq[key] = e
+    json.dump({"note": "rocprofv3 --pmc SQ_* --kernel-trace (own pass); means per launch; wave fractions are shares of SQ_WAVE_CYCLES "
+                       "(parked at s_waitcnt / barrier, issue-stalled, issuing)", "kernels": sq},
+              open(os.path.join(dst, f"{tag}_pmc_sq.json"), "w"), indent=1)

@@ -398,49 +398,3 @@ extern "C" int spamtree_mv_mcmc_c(const st_problem *pb, const st_options *opt, c
   stm_destroy(c);
   return rc;
 }
-
-#ifdef SPAMTREE_WITH_RCPP
-// Compiled only inside R (Rcpp + RcppArmadillo present): keeps the reference's exported symbol, arity and returned
-// names (/root/reference/src/RcppExports.cpp:112-154, spamtree_fit.cpp:403-414).  See INTEGRATION.md.
-#include <RcppArmadillo.h>
-// [[Rcpp::export]]
-Rcpp::List spamtree_mv_mcmc(const arma::mat &y, const arma::mat &X, const arma::mat &Z, const arma::mat &coords, const arma::uvec &mv_id,
-                            const arma::uvec &blocking, const arma::uvec &gix_block, const arma::uvec &res_is_ref,
-                            const arma::field<arma::uvec> &parents, const arma::field<arma::uvec> &children, bool limited_tree,
-                            const arma::vec &layer_names, const arma::vec &layer_gibbs_group, const arma::field<arma::uvec> &indexing,
-                            const arma::mat &set_unif_bounds_in, const arma::mat &start_w, const arma::vec &theta, const arma::vec &beta,
-                            const double &tausq, const arma::mat &mcmcsd, int mcmc_keep, int mcmc_burn, int mcmc_thin, int num_threads,
-                            char use_alg, bool adapting, bool main_verbose, bool verbose, bool debug, bool printall, bool sample_beta,
-                            bool sample_tausq, bool sample_theta, bool sample_w, bool sample_predicts) {
-  auto csr = [](const arma::field<arma::uvec> &f, std::vector<int64_t> &ptr, std::vector<int64_t> &idx) {
-    ptr.assign(f.n_elem + 1, 0);
-    for (arma::uword i = 0; i < f.n_elem; ++i) ptr[i + 1] = ptr[i] + (int64_t)f(i).n_elem;
-    idx.resize(ptr.back());
-    for (arma::uword i = 0; i < f.n_elem; ++i) for (arma::uword kk = 0; kk < f(i).n_elem; ++kk) idx[ptr[i] + kk] = (int64_t)f(i)(kk);
-  };
-  std::vector<int64_t> ip, ii, pp, pi, cp, ci, mv(mv_id.begin(), mv_id.end()), rr(res_is_ref.begin(), res_is_ref.end()),
-      bn(layer_names.n_elem), bg(layer_gibbs_group.n_elem);
-  for (size_t i = 0; i < bn.size(); ++i) { bn[i] = (int64_t)layer_names(i); bg[i] = (int64_t)layer_gibbs_group(i); }
-  csr(indexing, ip, ii); csr(parents, pp, pi); csr(children, cp, ci);
-  const int q = (int)Z.n_cols, p = (int)X.n_cols, k = (int)theta.n_elem;
-  st_problem pb = {(int64_t)coords.n_rows, (int32_t)coords.n_cols, q, p, (int32_t)rr.size(), (int64_t)bn.size(), y.memptr(), X.memptr(),
-                   coords.memptr(), mv.data(), rr.data(), bn.data(), bg.data(), ip.data(), ii.data(), pp.data(), pi.data(), cp.data(), ci.data()};
-  st_options opt = {0, 1, 0, 1, 0, limited_tree ? 2 : 0};
-  stm_flags fl = {adapting, sample_beta, sample_tausq, sample_theta, sample_w, sample_predicts};
-  arma::cube beta_mcmc(p, mcmc_keep, q, arma::fill::zeros);
-  arma::mat tausq_mcmc(q, mcmc_keep, arma::fill::zeros), theta_mcmc(k, mcmc_keep, arma::fill::zeros), paramsd(k, k, arma::fill::zeros);
-  arma::mat w_all(coords.n_rows, mcmc_keep, arma::fill::zeros), yhat_all(coords.n_rows, mcmc_keep, arma::fill::zeros);
-  double mcmc_time = 0;
-  const uint64_t seed = (uint64_t)std::floor(R::runif(0, 1) * 9007199254740992.0);   // chain seed from R's generator (set.seed applies)
-  const int rc = spamtree_mv_mcmc_c(&pb, &opt, set_unif_bounds_in.memptr(), theta.memptr(), k, beta.memptr(), tausq, mcmcsd.memptr(), mcmc_keep,
-                                    mcmc_burn, mcmc_thin, seed, &fl, w_all.memptr(), yhat_all.memptr(), beta_mcmc.memptr(), tausq_mcmc.memptr(),
-                                    theta_mcmc.memptr(), paramsd.memptr(), &mcmc_time);
-  if (rc == STM_ERR_NAN) throw 1;                                      // spamtree_fit.cpp:234-237
-  if (rc != 0) return Rcpp::List::create(Rcpp::Named("None") = arma::zeros(0));   // :416-428
-  arma::field<arma::mat> w_mcmc(mcmc_keep), yhat_mcmc(mcmc_keep);
-  for (int i = 0; i < mcmc_keep; ++i) { w_mcmc(i) = w_all.col(i); yhat_mcmc(i) = yhat_all.col(i); }
-  return Rcpp::List::create(Rcpp::Named("w_mcmc") = w_mcmc, Rcpp::Named("yhat_mcmc") = yhat_mcmc, Rcpp::Named("beta_mcmc") = beta_mcmc,
-                            Rcpp::Named("tausq_mcmc") = tausq_mcmc, Rcpp::Named("theta_mcmc") = theta_mcmc, Rcpp::Named("paramsd") = paramsd,
-                            Rcpp::Named("mcmc_time") = mcmc_time);
-}
-#endif
