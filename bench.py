@@ -34,21 +34,40 @@ def reference_cost(wl):
     return float(np.sum(4 * m * P * P + 2 * m * m * P + m ** 3 + np.where(has_ch, (P + m) ** 3, 0.0)))
 
 
+def mem_available_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                return float(ln.split()[1]) / 1024.0 ** 2
+    except Exception:      # noqa: BLE001
+        pass
+    return 0.0
+
+
 def cpu_baseline(full_wl, side, seconds_budget=20.0):
-    """oracle/refcpu (OpenMP restatement of the reference algorithm as written, kind="port") timed on the host cores
-    on a bounded sample: full iterations (B + C + A + statistics) of a smaller grid of the same family, then scaled to
-    the n=1e6 workload with the reference's own cost law.  Allocation/page-touch of its caches is not timed."""
+    """oracle/refcpu (OpenMP restatement of the reference algorithm as written, kind="port") timed on the host cores on a
+    bounded sample: full iterations (B + C + A + statistics).  When the host has the memory for the reference's caches at
+    the FULL workload (about 160 GB at n = 1e6: two copies of every dense per-block matrix, profiles/r02/cpu_scaling.json)
+    the sample is a few iterations of the full workload itself -- nothing is extrapolated; otherwise a smaller grid of the
+    same family, scaled with the reference's own cost law (exponent 0.99 against measurements at five sizes, same file).
+    Allocation / page-touch of the caches is not timed."""
     from oracle.refcpu import RefCpu
     from spamtree_amd.synthetic import make_workload
     # the GPU box gives one GPU's job a 16-CPU share; the reference's README runs num_threads = 10
     cores = int(os.environ.get("SPAMTREE_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-    wl = make_workload(side)
+    need_gb = 165.0 * full_wl["n"] / 1.0e6 * (full_wl["q"] ** 2 if full_wl["q"] > 1 else 1)
+    direct = os.environ.get("SPAMTREE_CPU_DIRECT", "1") != "0" and mem_available_gb() > need_gb + 30.0 and need_gb < 200.0
+    wl = full_wl if direct else make_workload(side)
+    if direct:
+        seconds_budget = 10.0
     rc = RefCpu(wl["y"], wl["X"], wl["coords"], wl["mv_id"], wl["res_is_ref"], wl["parents"], wl["children"],
                 wl["block_names"], wl["block_groups"], wl["indexing"], threads=cores)
     rc.set_tausq_inv(10.0)
-    rc.set_beta(np.zeros((wl["p"], 1)))
+    rc.set_beta(np.zeros((wl["p"], wl["q"])))
     rng = np.random.default_rng(1)
     rc.factor(0, wl["theta"])
+    if direct:
+        rc.factor(1, wl["theta"])       # touch the second cache copy before the clock starts
     its, t0 = 0, time.perf_counter()
     while True:
         rc.sample_w(rng.standard_normal(wl["n"]))
@@ -57,10 +76,10 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
         rc.stats()
         its += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget or its >= 400:
+        if (dt > seconds_budget and its >= 3) or its >= 400:
             break
     rc.close()
-    ratio = reference_cost(wl) / reference_cost(full_wl)
+    ratio = 1.0 if direct else reference_cost(wl) / reference_cost(full_wl)
     scaling = None
     try:      # measured at several sizes on a GPU box's host by profiles/cpu_scaling.py (committed): fitted exponent vs the law
         import glob
@@ -72,9 +91,12 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
         scaling = None
     return {"value": its / dt * ratio, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port", "host": host_cpu(),
             "scaling_check": scaling,
-            "sample": f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the {side}^2 grid (n={wl['n']}) in "
-                      f"{dt:.1f} s = {its / dt:.3f} it/s measured; scaled by the reference cost law "
-                      f"(sum (P+m)^3 + 4mP^2 + ...) ratio {ratio:.4f} to n={full_wl['n']}",
+            "sample": (f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the FULL workload (n={wl['n']}) in {dt:.1f} s: "
+                       "measured, not extrapolated" if direct else
+                       f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the {side}^2 grid (n={wl['n']}) in "
+                       f"{dt:.1f} s = {its / dt:.3f} it/s measured; scaled by the reference cost law "
+                       f"(sum (P+m)^3 + 4mP^2 + ...) ratio {ratio:.4f} to n={full_wl['n']}"),
+            "extrapolated": not direct,
             "measured_it_per_s_at_sample": its / dt, "sample_n": int(wl["n"])}
 
 

@@ -1626,6 +1626,92 @@ __global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Phase B, the theta-only part of the messages on its own: Gram part of a group's records, N_a' N_a + the children's
+// (spamtree_model.cpp:1162, 1190-1192: G_u[a, a]; SURVEY.md Q4: it depends on the accepted theta only).  Launched per level,
+// leaves first, on the first sweep after a factorisation of the accepted slot; the sweep itself then always takes the lean
+// kernels.  The panel is NOT staged: a wave owns one 16 x 16 tile of one ancestor's Gram matrix and reads its MFMA operands
+// straight from global memory / L2 (16 consecutive doubles per panel row and lane group), every load of the tile in
+// flight before the first MFMA; LDS holds the descriptor only, so eight workgroups share a CU.  Same arithmetic and
+// summation order as the Gram section of k_sample_mfma (bit-identical records).
+__global__ __launch_bounds__(NT, 6) void k_gram(SampleFastArgs A) {
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32];
+  __shared__ int s_bld[32];
+  __shared__ long long s_coff[64];
+  __shared__ long long s_gd[GD_MAXW];
+  __shared__ long long s_rowoff[32];   // panel offset of the group's row r
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const int M = B0.M, J = B0.nanc;
+  __syncthreads();
+  if (tid < 32) {
+    long long off = 0;
+    if (tid < M) {
+      const long long r = B0.row0 + tid;
+      int bi = 0;
+      while (bi + 1 < B0.nblk && r >= s_brow[bi + 1]) ++bi;
+      off = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+    }
+    s_rowoff[tid] = off;
+  }
+  __syncthreads();
+  const int nsteps = (M + 3) >> 2;          // <= 8
+  const int nfw = A.no_fwd ? 0 : B0.ndch;
+  double *rec = A.acc + B0.acc_off;
+  for (int u = wid; u < J * 4; u += NT / 64) {
+    const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
+    const int ma = s_am[t], oa = s_ao[t];
+    if (it * 16 >= ma || jt * 16 >= ma) continue;
+    double av_[8], bv_[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int r = 4 * st + l4;
+      const bool rok = st < nsteps && r < M;   // columns past the ancestor's m only feed discarded entries
+      const double *row = A.panels + s_rowoff[min(r, 31)] + oa + l15;
+      av_[st] = rok ? row[it * 16] : 0.0;
+      bv_[st] = rok ? row[jt * 16] : 0.0;
+    }
+    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+      if (st < nsteps) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av_[st], bv_[st], c, 0, 0, 0);
+    double *out = rec + s_aoff[t];
+    double chv[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < nfw; c0 += 4) {   // children's records: chunks of four in flight, fixed summation order
+      double ld4[4][4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+          ld4[cc][r] = (c0 + cc < nfw && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, nfw - 1)] + s_aoff[t] + i * ma + j] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) chv[r] += ld4[cc][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+      if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Phase B, fast path, sweeps that keep the cached Gram parts (do_gram == 0: every sweep between two accepted theta).
 // Same results as k_sample_mfma up to rounding, but the panel is never staged in LDS: it is read twice from global
 // memory (L2 / Infinity Cache the second time) with a thread mapping chosen per pass --
@@ -2326,6 +2412,7 @@ struct st_handle_s {
   long long n_summary = 0;
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
+  int split_gram = 1;                         // sweeps that rebuild the Gram parts: k_gram + lean kernels (SPAMTREE_SPLIT_GRAM=0: k_sample_mfma)
   bool stats_valid = false;                   // d_stats matches the current w and XB
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
   std::vector<double> host_stats;
@@ -3144,6 +3231,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     const char *e = getenv("SPAMTREE_FACTOR_KERNEL");
     h->factor_gen = (e && e[0] == '1') ? 1 : 3;
     { const char *e2 = getenv("SPAMTREE_SAMPLE_LEAN"); h->sample_lean = (e2 && e2[0] == '0') ? 0 : 1; }
+    { const char *e2 = getenv("SPAMTREE_SPLIT_GRAM"); h->split_gram = (e2 && e2[0] == '0') ? 0 : 1; }
   }
   {
     // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
@@ -3727,7 +3815,12 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.acc = h->d_acc.p; F.errflag = h->d_err.p; F.ldN = L.ldN; F.Mr4 = L.Mr4; F.Mrows = L.Mrows; F.maxP = L.maxP; F.av_dbl = L.av_dbl;
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
-        if (F.do_gram || h->sample_lean == 0 || (!L.isref && L.maxP > 255)) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
+        const bool lean_ok = h->sample_lean != 0 && !(!L.isref && L.maxP > 255);
+        if (F.do_gram && lean_ok && h->split_gram) {   // the theta-only Gram parts on their own (k_gram), then the lean sweep kernels
+          hipLaunchKernelGGL(k_gram, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
+          F.do_gram = 0;
+        }
+        if (F.do_gram || !lean_ok) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
         else if (!L.isref) hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
         else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
       } else if (L.big_sample) {
