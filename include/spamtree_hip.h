@@ -174,6 +174,12 @@ int st_cross_covariance_ag10(const double *coords1, const int64_t *mv1, int64_t 
 int st_summary_reset(st_handle h);
 int st_summary_accumulate(st_handle h, uint64_t seed, uint32_t iter);
 int st_summary_get(st_handle h, double *w_mean, double *yhat_mean, int64_t *n_accumulated);
+/* Posterior quantiles on the device (list_qtile / prctile_stl, /root/reference/src/list_mean.cpp:62-137: per row, the order
+ * statistics around q * keep of the `keep` saved draws, interpolated by the reference's rule).  st_summary_reserve(keep) keeps
+ * the draws of the next `keep` st_summary_accumulate calls in HBM (2 x keep x n_all doubles: w and yhat; keep <= 16384;
+ * keep = 0 frees them); st_summary_quantile sorts every row's draws in LDS.  Either output may be NULL. */
+int st_summary_reserve(st_handle h, int64_t keep);
+int st_summary_quantile(st_handle h, double q, double *w_q, double *yhat_q);
 
 int st_set_stream(st_handle h, void *stream);              /* launch on the caller's stream (the one its collectives use) */
 

@@ -76,6 +76,8 @@ SIGNATURES = {
     "st_summary_reset": (C.c_int, [H]),
     "st_summary_accumulate": (C.c_int, [H, C.c_uint64, C.c_uint32]),
     "st_summary_get": (C.c_int, [H, c_dp, c_dp, c_ip]),
+    "st_summary_reserve": (C.c_int, [H, C.c_int64]),
+    "st_summary_quantile": (C.c_int, [H, C.c_double, c_dp, c_dp]),
     "st_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int32]),
     "st_comm_init": (C.c_int, [H, C.c_void_p]),
 }

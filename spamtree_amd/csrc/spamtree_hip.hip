@@ -2309,6 +2309,67 @@ __global__ void k_cross_cov(const double *c1, const int *mv1, long long n1, cons
   const long long j = blockIdx.y;
   if (i < n1 && j < n2) out[j * n1 + i] = cov_entry(cp, c1[i], c1[n1 + i], mv1[i], c2[j], c2[n2 + j], mv2[j]);
 }
+// Posterior quantiles per row over the saved draws (list_qtile / prctile_stl, /root/reference/src/list_mean.cpp:62-137):
+// draws[d * n + row], d < keep.  A workgroup sorts the draws of R rows in LDS (bitonic, rows padded to Kpad = 2^k with +inf)
+// and applies the reference's interpolation rule between the two order statistics around r = q * keep.
+struct QtArgs {
+  const double *draws;
+  long long n;
+  int keep, Kpad, R;
+  double q;
+  double *out;
+};
+__global__ __launch_bounds__(NT) void k_qtile(QtArgs A) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, R = A.R, K = A.Kpad;
+  const long long row0 = (long long)blockIdx.x * R;
+  for (int idx = tid; idx < R * K; idx += NT) {
+    const int d = idx / R, r = idx - d * R;   // R consecutive rows of one draw: contiguous in memory
+    double v = __builtin_inf();
+    if (d < A.keep && row0 + r < A.n) v = A.draws[(size_t)d * A.n + row0 + r];
+    lds[(size_t)r * K + d] = v;
+  }
+  __syncthreads();
+  const int half = K >> 1;
+  for (int k = 2; k <= K; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int p = tid; p < R * half; p += NT) {
+        const int r = p / half, i = p - r * half;
+        const int i1 = 2 * j * (i / j) + (i % j), i2 = i1 + j;
+        double *a = lds + (size_t)r * K;
+        const double x = a[i1], y = a[i2];
+        const bool up = (i1 & k) == 0;
+        if ((x > y) == up) { a[i1] = y; a[i2] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid < R && row0 + tid < A.n) {
+    const double *a = lds + (size_t)tid * K;
+    const int len = A.keep;
+    // prctile_stl: r = percent / 100 * len with percent = q * 100 (cqtile); every product rounded on its own -- a fused
+    // q * len - 1 would see 0.025 * 40 as 1 + 5.6e-17 and pick the other pair of order statistics
+    double r = A.q * 100.0, lower, upper;
+    asm volatile("" : "+v"(r));   // (an empty asm after each step keeps the optimiser from contracting across it)
+    r = r / 100.0;
+    asm volatile("" : "+v"(r));
+    r = r * (double)len;
+    asm volatile("" : "+v"(r));
+    if (r >= len / 2.0) {
+      const int lo = (int)fmax(r - 1.0, 0.0);
+      lower = a[lo];
+      upper = lo < len - 1 ? a[lo + 1] : lower;
+    } else {
+      const int up = (int)ceil(fmax(r - 1.0, 0.0));
+      upper = a[up];
+      lower = up > 0 ? a[up - 1] : upper;
+    }
+    const int k = (int)(r + 0.5);                    // implicit floor
+    r = r - k;
+    A.out[row0 + tid] = (0.5 - r) * lower + (0.5 + r) * upper;
+  }
+}
+
 __global__ void k_axpy_sum(double *acc, const double *x, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) acc[i] += x[i];
@@ -2410,6 +2471,8 @@ struct st_handle_s {
   bool ext_stream = false;
   DevBuf<double> d_sum_w, d_sum_yhat;         // running sums over saved iterations (st_summary_*)
   long long n_summary = 0;
+  DevBuf<double> d_draws_w, d_draws_yhat;     // st_summary_reserve: the saved draws themselves, [keep][n_all] (quantiles)
+  long long draws_cap = 0, n_draws = 0;
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   int split_gram = 1;                         // sweeps that rebuild the Gram parts: k_gram + lean kernels (SPAMTREE_SPLIT_GRAM=0: k_sample_mfma)
@@ -2551,7 +2614,7 @@ extern "C" int st_destroy(st_handle h) {
   if (h->ev_top) (void)hipEventDestroy(h->ev_top);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
   if (h->ev_stats) (void)hipEventDestroy(h->ev_stats);
-  if (h->stream2) (void)hipStreamDestroy(h->stream2); h->d_sum_w.free(); h->d_sum_yhat.free();
+  if (h->stream2) (void)hipStreamDestroy(h->stream2); h->d_sum_w.free(); h->d_sum_yhat.free(); h->d_draws_w.free(); h->d_draws_yhat.free();
   prof_harvest(h);
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
@@ -4252,7 +4315,7 @@ extern "C" int st_summary_reset(st_handle h) {
   if (!h->d_sum_w.p) { HCHK(h, h->d_sum_w.alloc(h->n_all)); HCHK(h, h->d_sum_yhat.alloc(h->n_all)); }
   HCHK(h, hipMemsetAsync(h->d_sum_w.p, 0, h->n_all * sizeof(double), h->stream));
   HCHK(h, hipMemsetAsync(h->d_sum_yhat.p, 0, h->n_all * sizeof(double), h->stream));
-  h->n_summary = 0;
+  h->n_summary = 0; h->n_draws = 0;
   return ST_OK;
 }
 extern "C" int st_summary_accumulate(st_handle h, uint64_t seed, uint32_t iter) {   // yhat noise: device stream 5 (spamtree_fit.cpp:384)
@@ -4266,7 +4329,47 @@ extern "C" int st_summary_accumulate(st_handle h, uint64_t seed, uint32_t iter) 
   hipLaunchKernelGGL(k_axpy_sum, dim3(grid), dim3(NT), 0, h->stream, h->d_sum_yhat.p, h->d_tmp_n.p, h->n_all);
   hipLaunchKernelGGL(k_axpy_sum, dim3(grid), dim3(NT), 0, h->stream, h->d_sum_w.p, h->d_w.p, h->n_all);
   HCHK(h, hipGetLastError());
+  if (h->n_draws < h->draws_cap) {   // keep the draw itself for the quantiles (device order, one contiguous row per draw)
+    HCHK(h, hipMemcpyAsync(h->d_draws_w.p + (size_t)h->n_draws * h->n_all, h->d_w.p, h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HCHK(h, hipMemcpyAsync(h->d_draws_yhat.p + (size_t)h->n_draws * h->n_all, h->d_tmp_n.p, h->n_all * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->n_draws += 1;
+  }
   h->n_summary += 1;
+  return ST_OK;
+}
+extern "C" int st_summary_reserve(st_handle h, int64_t keep) {
+  if (!h || keep < 0) return ST_ERR_USAGE;
+  HCHK(h, hipSetDevice(h->device));
+  HCHK(h, hipStreamSynchronize(h->stream));
+  h->d_draws_w.free(); h->d_draws_yhat.free();
+  h->draws_cap = 0; h->n_draws = 0;
+  if (keep == 0) return ST_OK;
+  if (keep > 16384) { h->err = "st_summary_reserve: at most 16384 saved draws (one row's draws are sorted in one workgroup's LDS)"; return ST_ERR_UNSUPPORTED; }
+  HCHK(h, h->d_draws_w.alloc((size_t)keep * h->n_all));
+  HCHK(h, h->d_draws_yhat.alloc((size_t)keep * h->n_all));
+  h->draws_cap = keep;
+  return ST_OK;
+}
+extern "C" int st_summary_quantile(st_handle h, double q, double *w_q, double *yhat_q) {
+  if (!h || !(q >= 0.0 && q <= 1.0)) return ST_ERR_USAGE;
+  if (h->n_draws == 0) { h->err = "no draw stored: call st_summary_reserve before the saved iterations"; return ST_ERR_USAGE; }
+  HCHK(h, hipSetDevice(h->device));
+  int Kpad = 2;
+  while (Kpad < h->n_draws) Kpad <<= 1;
+  const int R = std::max(1, std::min(8, (int)(128 * 1024 / ((size_t)Kpad * 8))));
+  const size_t lds = (size_t)R * Kpad * sizeof(double);
+  (void)hipFuncSetAttribute((const void *)k_qtile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_limit);
+  for (int which = 0; which < 2; ++which) {
+    double *dst = which == 0 ? w_q : yhat_q;
+    if (!dst) continue;
+    QtArgs A;
+    A.draws = which == 0 ? h->d_draws_w.p : h->d_draws_yhat.p; A.n = h->n_all; A.keep = (int)h->n_draws; A.Kpad = Kpad; A.R = R; A.q = q;
+    A.out = h->d_tmp_n.p;
+    hipLaunchKernelGGL(k_qtile, dim3((unsigned)((h->n_all + R - 1) / R)), dim3(NT), lds, h->stream, A);
+    HCHK(h, hipGetLastError());
+    const int rc = download_rows(h, h->d_tmp_n.p, dst);
+    if (rc) return rc;
+  }
   return ST_OK;
 }
 extern "C" int st_summary_get(st_handle h, double *w_mean, double *yhat_mean, int64_t *n_accumulated) {

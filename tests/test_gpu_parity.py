@@ -233,22 +233,43 @@ def test_cross_covariance_ag10_export():
         CrossCovarianceAG10(p1, np.ones(70), p2, np.ones(55), [1.0], [0.1], [1.0], [5.0], np.zeros((1, 1)))
 
 
-def test_running_posterior_means():
+@pytest.mark.parametrize("keep", [7, 40])
+def test_posterior_means_and_quantiles_match_oracle_chain(keep):
+    """Running means and per-row quantiles of the saved draws on the device against list_mean / list_qtile
+    (/root/reference/src/list_mean.cpp:10-30, 62-137) applied to the ORACLE's draws of the same sweeps (same Philox streams):
+    w and yhat = XB + w + tausq^(1/2) * normal (spamtree_fit.cpp:384)."""
     import ctypes as C
+    from oracle.list_summaries import list_mean, list_qtile
+    from oracle.spamtree_oracle import StRng
     from spamtree_amd.model import _dp
     pb = make_problem(side=25, q=1, seed=8, missing=0.1)
-    hm = hip_model(pb, tausq=0.2)
-    assert hm.get_loglik_comps_w(0)
+    beta = np.array([0.3, -0.2, 0.1])
+    om = oracle_model(pb, tausq=0.2, beta=beta)
+    hm = hip_model(pb, tausq=0.2, beta=beta)
+    assert om.get_loglik_comps_w(om.param_data) and hm.get_loglik_comps_w(0)
+    rng_o = StRng(3)
     ws, ys = [], []
     assert hm.lib.st_summary_reset(hm.h) == 0
-    for it in range(4):
+    assert hm.lib.st_summary_reserve(hm.h, keep) == 0
+    for it in range(keep):
+        om.gibbs_sample_w(rng_o.sweep_normals(it, pb["n"]))
+        om.predict(True)
         hm.deal_with_w(None, seed=3, it=it)
-        ws.append(hm.get_w().copy()); ys.append(hm.yhat(None, seed=3, it=it))
+        hm.predict(True)
+        ws.append(om.w.copy())
+        ys.append(om.XB + om.w + np.sqrt(1.0 / om.tausq_inv_long) * rng_o.yhat_normals(it, pb["n"]))
         assert hm.lib.st_summary_accumulate(hm.h, 3, it) == 0
     wm, ym = np.zeros(pb["n"]), np.zeros(pb["n"])
     cnt = C.c_int64()
-    assert hm.lib.st_summary_get(hm.h, _dp(wm), _dp(ym), C.byref(cnt)) == 0 and cnt.value == 4
-    assert np.abs(wm - np.mean(ws, axis=0)).max() < 1e-13 and np.abs(ym - np.mean(ys, axis=0)).max() < 1e-13
+    assert hm.lib.st_summary_get(hm.h, _dp(wm), _dp(ym), C.byref(cnt)) == 0 and cnt.value == keep
+    assert relerr(wm, list_mean(ws)) <= REL and relerr(ym, list_mean(ys)) <= REL
+    for q in (0.025, 0.5, 0.975, 0.0, 1.0, 0.3):
+        wq, yq = np.zeros(pb["n"]), np.zeros(pb["n"])
+        assert hm.lib.st_summary_quantile(hm.h, q, _dp(wq), _dp(yq)) == 0
+        assert relerr(wq, list_qtile(ws, q)) <= REL, q
+        assert relerr(yq, list_qtile(ys, q)) <= REL, q
+    assert hm.lib.st_summary_reserve(hm.h, 0) == 0
+    assert hm.lib.st_summary_quantile(hm.h, 0.5, _dp(wm), None) < 0       # nothing stored any more
     hm.close()
 
 

@@ -243,3 +243,24 @@ def test_short_chain_runs_and_is_deterministic():
     assert np.array_equal(r1["w_mcmc"][-1], r2["w_mcmc"][-1])
     assert np.all(np.isfinite(r1["beta_mcmc"])) and np.all(r1["tausq_mcmc"] > 0)
     assert np.all(np.isfinite(r1["yhat_mcmc"][-1]))
+
+
+def test_list_qtile_restatement_against_numpy_order_statistics():
+    """oracle/list_summaries.py (list_mean.cpp:62-137): the rule is an interpolation between two ADJACENT order statistics
+    around q * n (integer truncation included: not MATLAB's prctile); at the extremes the minimum / maximum."""
+    from oracle.list_summaries import list_mean, list_qtile, prctile_stl
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 40, 101):
+        v = rng.standard_normal(n)
+        s = np.sort(v)
+        for q in (0.0, 0.025, 0.3, 0.5, 0.75, 0.975, 1.0):
+            got = prctile_stl(v, q * 100.0)
+            assert s[0] - 1e-12 <= got <= s[-1] + 1e-12
+            j = np.searchsorted(s, got, side="left")
+            assert any(abs(got - s[k]) < 1e-12 for k in range(n)) or (s[j - 1] <= got <= s[j])   # between neighbours
+        if n == 5:      # worked by hand from the source: r = 2.5, idx_lo = int(1.5) = 1, k = 3, weight (0.5 - (-0.5)) on the
+            assert prctile_stl(v, 50.0) == s[1]          # lower one: the reference's "median" of five is the SECOND smallest
+        assert prctile_stl(v, 0.0) == s[0] and prctile_stl(v, 100.0) == s[-1]
+    x = [rng.standard_normal((6, 1)) for _ in range(9)]
+    assert np.allclose(list_mean(x), sum(x) / 9)
+    assert list_qtile(x, 0.5).shape == (6, 1)
