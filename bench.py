@@ -266,7 +266,7 @@ def main():
 
     t_setup = time.time()
     missing = tuple(float(x) for x in args.missing.split(",")) if args.missing else None
-    wl = make_workload(args.side, q=args.q, cell_size=args.cell_size, missing=missing)
+    wl = make_workload(args.side, q=args.q, cell_size=args.cell_size, missing=missing, device=local_rank)
     # N > 1: one problem shared by all ranks -- subtrees below a cut level are owned by one GPU, the top is replicated,
     # exchanges are RCCL all-reduces issued by the library on its own stream (include/spamtree_hip.h, multi-GPU section)
     k = wl["theta"].size

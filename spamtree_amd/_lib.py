@@ -103,6 +103,14 @@ SIGNATURES.update({
                                      c_dp, c_dp, c_dp, c_dp, c_dp]),
 })
 
+# include/spamtree_tree.h (device parts of the tree builder)
+c_i32p = C.POINTER(C.c_int32)
+SIGNATURES.update({
+    "st_tb_sort": (C.c_int, [c_dp, C.c_int64, C.c_int32, c_dp]),
+    "st_tb_cell_argmin": (C.c_int, [c_ip, c_dp, c_ip, C.c_int64, C.c_int64, C.c_int32, c_ip]),
+    "st_tb_nearest": (C.c_int, [c_dp, c_dp, c_i32p, C.c_int64, c_dp, c_dp, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_ip]),
+})
+
 _lib = None
 
 

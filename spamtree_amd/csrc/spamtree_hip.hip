@@ -2600,6 +2600,7 @@ static size_t lds_sample_bytes(int maxP, int maxM, int maxLd, bool big) {
 static size_t lds_loglik_bytes(int maxP, int maxM) { return ((size_t)maxP + 2 * (size_t)maxM) * 8 + 64; }
 
 extern "C" const char *st_last_error(st_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+extern "C" void st_set_create_error(const char *msg) { g_create_error = msg ? msg : ""; }   // other translation units of the library
 
 extern "C" int st_destroy(st_handle h) {
   if (!h) return ST_OK;

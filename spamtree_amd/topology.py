@@ -15,6 +15,16 @@ fine cell is the remaining row nearest to the cell centre (ties -> lowest origin
 always yields the same tree on any machine.  Block numbering inside a level follows the (first axis fastest)
 cell order rather than R's string-sorted factor levels.  The *contract* handed to the model (0-based
 ``indexing``, ascending ``parents`` / ``children``, ``block_groups``, ``res_is_ref``) is the reference's.
+
+``mvbias`` (make_tree.R:7-14): the reference draws the knot of a fine cell with probability proportional to
+n_margin^(-mvbias) (sparser outcomes are preferred for the upper levels).  The deterministic counterpart here: the knot
+minimises d^2 * (n_margin / n_max)^mvbias, d = distance to the cell centre -- mvbias = 0 is the plain nearest-to-centre
+rule, a large mvbias picks the sparsest margin present in the cell.
+
+``device`` (make_tree / prepare): the row-parallel steps -- order statistics for the thresholds, one knot per fine cell,
+same-margin nearest placed row -- run on the GPU through include/spamtree_tree.h (``st_tb_sort``, ``st_tb_cell_argmin``,
+``st_tb_nearest``); the tree is IDENTICAL to the host path's (tests/test_gpu_tree.py).  Nearest-row ties go to the lowest
+row id on both paths (FNN's tie order in the reference is unspecified).
 """
 from __future__ import annotations
 
@@ -29,15 +39,95 @@ __all__ = [
 ]
 
 
-def kthresholds(x: np.ndarray, k: int) -> np.ndarray:
-    """k-1 order-statistic thresholds: element ``i*n//k`` of sorted ``x`` (tree_dep.cpp:16-27)."""
+def kthresholds(x: np.ndarray, k: int, presorted: bool = False) -> np.ndarray:
+    """k-1 order-statistic thresholds: element ``i*n//k`` of sorted ``x`` (tree_dep.cpp:16-27).
+    ``presorted``: ``x`` is already ascending (make_tree sorts every axis once, on the host or with ``st_tb_sort``)."""
     x = np.asarray(x, dtype=np.float64)
     n = x.size
     if k <= 1 or n == 0:
         return np.zeros(0)
-    xs = np.sort(x, kind="stable")
+    xs = x if presorted else np.sort(x, kind="stable")
     q = (np.arange(1, k, dtype=np.int64) * n) // k
     return xs[q]
+
+
+def _device_lib(device):
+    if device is None:
+        return None
+    from . import _lib
+    return _lib.load()
+
+
+def _sorted_axis(x, device):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lib = _device_lib(device)
+    if lib is None or x.size == 0:
+        return np.sort(x, kind="stable")
+    from . import _lib
+    out = np.empty_like(x)
+    rc = lib.st_tb_sort(x.ctypes.data_as(_lib.c_dp), x.size, int(device), out.ctypes.data_as(_lib.c_dp))
+    if rc != 0:
+        raise RuntimeError(f"st_tb_sort failed ({rc}): {lib.st_last_error(None).decode()}")
+    return out
+
+
+def _cell_argmin(code, key, ix, ncells, device):
+    """Row index (into the arrays given) of the row minimising (key, ix) in every occupied cell, cells ascending."""
+    lib = _device_lib(device)
+    if lib is None:
+        order = np.lexsort((ix, key, code))
+        first = np.ones(order.size, dtype=bool)
+        first[1:] = code[order][1:] != code[order][:-1]
+        return order[first]
+    from . import _lib
+    code = np.ascontiguousarray(code, dtype=np.int64); key = np.ascontiguousarray(key, dtype=np.float64)
+    ix = np.ascontiguousarray(ix, dtype=np.int64)
+    out = np.empty(int(ncells), dtype=np.int64)
+    rc = lib.st_tb_cell_argmin(code.ctypes.data_as(_lib.c_ip), key.ctypes.data_as(_lib.c_dp), ix.ctypes.data_as(_lib.c_ip), code.size,
+                               int(ncells), int(device), out.ctypes.data_as(_lib.c_ip))
+    if rc != 0:
+        raise RuntimeError(f"st_tb_cell_argmin failed ({rc}): {lib.st_last_error(None).decode()}")
+    return out[out >= 0]
+
+
+def _nearest_rows(tc, tmv, qc, qmv, n_margins, same_margin, device):
+    """For every query the index (into the targets) of the nearest target -- of the same margin when requested and present --
+    ties to the lowest target index."""
+    tc = np.ascontiguousarray(tc, dtype=np.float64); qc = np.ascontiguousarray(qc, dtype=np.float64)
+    if not same_margin:
+        tmv = np.zeros(tc.shape[0], dtype=np.int64); qmv = np.zeros(qc.shape[0], dtype=np.int64); n_margins = 1
+    lib = _device_lib(device)
+    if lib is not None and tc.shape[0] > 0 and qc.shape[0] > 0:
+        from . import _lib
+        tx, ty = np.ascontiguousarray(tc[:, 0]), np.ascontiguousarray(tc[:, 1])
+        qx, qy = np.ascontiguousarray(qc[:, 0]), np.ascontiguousarray(qc[:, 1])
+        t32, q32 = np.ascontiguousarray(tmv, dtype=np.int32), np.ascontiguousarray(qmv, dtype=np.int32)
+        out = np.empty(qc.shape[0], dtype=np.int64)
+        rc = lib.st_tb_nearest(tx.ctypes.data_as(_lib.c_dp), ty.ctypes.data_as(_lib.c_dp), t32.ctypes.data_as(_lib.c_i32p), tc.shape[0],
+                               qx.ctypes.data_as(_lib.c_dp), qy.ctypes.data_as(_lib.c_dp), q32.ctypes.data_as(_lib.c_i32p), qc.shape[0],
+                               int(n_margins), int(device), out.ctypes.data_as(_lib.c_ip))
+        if rc != 0:
+            raise RuntimeError(f"st_tb_nearest failed ({rc}): {lib.st_last_error(None).decode()}")
+        return out
+    from scipy.spatial import cKDTree
+    out = np.zeros(qc.shape[0], dtype=np.int64)
+    for vv in np.unique(qmv):
+        qsel = np.nonzero(qmv == vv)[0]
+        tsel = np.nonzero(tmv == vv)[0]
+        if tsel.size == 0:
+            tsel = np.arange(tc.shape[0])
+        k = int(min(9, tsel.size))
+        tree = cKDTree(tc[tsel])
+        _, nn = tree.query(qc[qsel], k=k)
+        nn = nn.reshape(qsel.size, k)
+        # exact squared distances in the arithmetic the device uses, ties to the lowest target index
+        cand = tsel[nn]
+        dx = qc[qsel, 0][:, None] - tc[cand, 0]
+        dy = qc[qsel, 1][:, None] - tc[cand, 1]
+        d2 = dx * dx + dy * dy
+        best = d2.min(axis=1)
+        out[qsel] = np.where(d2 == best[:, None], cand, np.iinfo(np.int64).max).min(axis=1)
+    return out
 
 
 def part_axis_parallel(coords: np.ndarray, thresholds: Sequence[np.ndarray]) -> np.ndarray:
@@ -60,6 +150,37 @@ def _cell_code(cells: np.ndarray, sizes: Sequence[int]) -> np.ndarray:
     return code
 
 
+def _unique_rows(a: np.ndarray) -> np.ndarray:
+    """Sorted unique rows of a small-integer matrix (what ``np.unique(a, axis=0)`` returns, by lexsort + adjacent compare
+    instead of a structured-dtype sort; two non-negative columns go through one combined 64-bit key)."""
+    a = np.asarray(a)
+    if a.shape[0] == 0:
+        return a.copy()
+    if a.shape[1] == 2 and a.min() >= 0 and int(a[:, 0].max()) < (1 << 31) and int(a[:, 1].max()) < (1 << 31):
+        key = np.unique((a[:, 0].astype(np.int64) << 32) | a[:, 1].astype(np.int64))
+        return np.column_stack([key >> 32, key & 0xffffffff]).astype(a.dtype)
+    order = np.lexsort(tuple(a[:, j] for j in range(a.shape[1] - 1, -1, -1)))
+    s_ = a[order]
+    keep = np.ones(s_.shape[0], dtype=bool)
+    keep[1:] = np.any(s_[1:] != s_[:-1], axis=1)
+    return s_[keep]
+
+
+def _coord_groups(coords: np.ndarray) -> np.ndarray:
+    """Index of every row's coordinate group (rows with identical coordinates), numbered in lexicographic coordinate order
+    (what ``np.unique(coords, axis=0, return_inverse=True)`` returns, without its structured-dtype sort)."""
+    n, dd = coords.shape
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    order = np.lexsort(tuple(coords[:, j] for j in range(dd - 1, -1, -1)))
+    cs = coords[order]
+    new = np.ones(n, dtype=bool)
+    new[1:] = np.any(cs[1:] != cs[:-1], axis=1)
+    g = np.empty(n, dtype=np.int64)
+    g[order] = np.cumsum(new) - 1
+    return g
+
+
 @dataclass
 class TreeResult:
     """Output of :func:`make_tree` (counterpart of make_tree.R:416-419)."""
@@ -76,14 +197,12 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
               start_level: int = 0, tree_depth: float = np.inf,
               last_not_reference: bool = True,
               cherrypick_same_margin: bool = True,
-              cherrypick_group_locations: bool = True) -> TreeResult:
+              cherrypick_group_locations: bool = True, mvbias: float = 0.0, device: Optional[int] = None) -> TreeResult:
     """Recursive axis-parallel partition with one knot per fine cell (make_tree.R:1-420).
 
     ``coords`` n x d, ``observed`` boolean (False = NA outcome, goes to the prediction level),
     ``mv_id`` 1-based outcome id per row.  Rows are identified by their position 0..n-1 (``ix``).
     """
-    from scipy.spatial import cKDTree
-
     coords = np.asarray(coords, dtype=np.float64)
     observed = np.asarray(observed, dtype=bool)
     mv_id = np.asarray(mv_id, dtype=np.int64)
@@ -99,8 +218,13 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
     hi = c_av.max(axis=0) if ix_av.size else np.ones(dd)
 
     # co-location groups (make_tree.R:95-100 joins by coordinates)
-    _, gix_all = np.unique(coords, axis=0, return_inverse=True)
-    gix_all = gix_all.reshape(-1)
+    gix_all = _coord_groups(coords)
+    # every axis of the available sample sorted ONCE: all thresholds of all levels are order statistics of it
+    sorted_axes = [_sorted_axis(c_av[:, i], device) for i in range(dd)]
+    # mvbias (make_tree.R:12-22): weight n_margin^(-mvbias) per outcome, here as a factor on the squared distance
+    n_marg = int(mv_id.max()) if mv_id.size else 1
+    cnt_marg = np.bincount(mv_id[ix_av] - 1, minlength=n_marg).astype(np.float64)
+    marg_factor = np.ones(n_marg) if mvbias == 0 else (np.maximum(cnt_marg, 1.0) / max(cnt_marg.max(), 1.0)) ** float(mvbias)
 
     remaining = np.ones(ix_av.size, dtype=bool)        # over available rows ("cx")
     ref_ix: List[np.ndarray] = []
@@ -116,7 +240,7 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
 
     while res <= max_res and remaining.any():
         n_rem = int(remaining.sum())
-        thr_knots = [kthresholds(c_av[:, i], axis_cell_size[i] * K[i] ** (res - 1)) for i in range(dd)]
+        thr_knots = [kthresholds(sorted_axes[i], axis_cell_size[i] * K[i] ** (res - 1), presorted=True) for i in range(dd)]
         sizes_k = [t.size + 1 for t in thr_knots]
         grid_size = int(np.prod(sizes_k))
         rem_idx = np.nonzero(remaining)[0]
@@ -129,10 +253,9 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
                 edges = np.concatenate(([lo[i]], thr_knots[i], [hi[i]]))
                 centre = 0.5 * (edges[cells[:, i] - 1] + edges[cells[:, i]])
                 d2 += (c_av[rem_idx, i] - centre) ** 2
-            order = np.lexsort((ix_av[rem_idx], d2, code))
-            first = np.ones(order.size, dtype=bool)
-            first[1:] = code[order][1:] != code[order][:-1]
-            chosen = rem_idx[order[first]]
+            if mvbias != 0:
+                d2 = d2 * marg_factor[mv_id[ix_av[rem_idx]] - 1]
+            chosen = rem_idx[_cell_argmin(code, d2, ix_av[rem_idx], grid_size, device)]
             if cherrypick_group_locations:
                 sel_g = np.zeros(gix_all.max() + 1, dtype=bool)
                 sel_g[gix_all[ix_av[chosen]]] = True
@@ -140,13 +263,13 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
             knots = np.sort(chosen)
         else:
             knots = rem_idx
-        thr_res = [kthresholds(c_av[:, i], K[i] ** (res - 1)) for i in range(dd)]
+        thr_res = [kthresholds(sorted_axes[i], K[i] ** (res - 1), presorted=True) for i in range(dd)]
         thresholds_list.append(thr_res)
         sizes_r = [t.size + 1 for t in thr_res]
         code_k = _cell_code(part_axis_parallel(c_av[knots], thr_res), sizes_r)
         present = np.unique(code_k)
         blk = max_block_number + 1 + np.searchsorted(present, code_k)
-        level_block_of_code.append({int(c): int(max_block_number + 1 + j) for j, c in enumerate(present)})
+        level_block_of_code.append((present, int(max_block_number + 1)))   # block of cell code c = base + rank of c in `present`
         max_block_number = int(blk.max())
         ref_ix.append(ix_av[knots]); ref_block.append(blk); ref_res.append(np.full(knots.size, res))
         remaining[knots] = False
@@ -170,36 +293,19 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
     paths = np.zeros((r_ix.size, n_lev), dtype=np.int64)
     for l in range(n_lev):
         codes = level_cells_of_avail[l][pos_in_av[r_ix]]
-        lut = level_block_of_code[l]
-        keys = np.fromiter(lut.keys(), dtype=np.int64, count=len(lut))
-        vals = np.fromiter(lut.values(), dtype=np.int64, count=len(lut))
-        o = np.argsort(keys)
-        keys, vals = keys[o], vals[o]
-        p = np.searchsorted(keys, codes)
-        p = np.clip(p, 0, keys.size - 1)
-        paths[:, l] = np.where(keys[p] == codes, vals[p], 0)
-    parchi = np.unique(paths, axis=0) if paths.size else np.zeros((0, n_lev), dtype=np.int64)
+        keys, base = level_block_of_code[l]
+        p = np.clip(np.searchsorted(keys, codes), 0, keys.size - 1)
+        paths[:, l] = np.where(keys[p] == codes, base + p, 0)
+    parchi = _unique_rows(paths) if paths.size else np.zeros((0, n_lev), dtype=np.int64)
 
     all_ix = [r_ix]; all_block = [r_block]; all_res = [r_res]
     res_is_ref_l = list(res_is_ref)
 
     def _nearest_block(target_ix, target_block, query_ix):
         """Nearest (same-margin if requested) placed row decides the block (make_tree.R:236, 256, 345, 367)."""
-        out = np.zeros(query_ix.size, dtype=np.int64)
-        if cherrypick_same_margin:
-            for vv in np.unique(mv_id[query_ix]):
-                qsel = mv_id[query_ix] == vv
-                tsel = mv_id[target_ix] == vv
-                if not tsel.any():
-                    tsel = np.ones(target_ix.size, dtype=bool)
-                tree = cKDTree(coords[target_ix[tsel]])
-                _, nn = tree.query(coords[query_ix[qsel]], k=1)
-                out[qsel] = target_block[tsel][nn]
-        else:
-            tree = cKDTree(coords[target_ix])
-            _, nn = tree.query(coords[query_ix], k=1)
-            out = target_block[nn]
-        return out
+        nn = _nearest_rows(coords[target_ix], mv_id[target_ix] - 1, coords[query_ix], mv_id[query_ix] - 1, n_marg,
+                           cherrypick_same_margin, device)
+        return target_block[nn]
 
     # leftovers (only when tree_depth is finite): one extra non-reference level under the deepest level
     if remaining.any():
@@ -211,10 +317,9 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
         blk = max_block_number + 1 + inv
         max_block_number = int(blk.max())
         all_ix.append(left_ix); all_block.append(blk); all_res.append(np.full(left_ix.size, top + 1))
-        col = np.zeros(parchi.shape[0], dtype=np.int64)
         first_new = max_block_number - uniq.size + 1
-        for j, parent in enumerate(uniq):
-            col[parchi[:, -1] == parent] = first_new + j
+        pp_ = np.clip(np.searchsorted(uniq, parchi[:, -1]), 0, uniq.size - 1)
+        col = np.where(uniq[pp_] == parchi[:, -1], first_new + pp_, 0).astype(np.int64)
         parchi = np.column_stack([parchi, col])
         res_is_ref_l.append(0)
 
@@ -233,14 +338,13 @@ def make_tree(coords: np.ndarray, observed: np.ndarray, mv_id: np.ndarray,
         miss_res = int(cur_res.max()) + 1
         all_ix.append(ix_mi); all_block.append(blk); all_res.append(np.full(ix_mi.size, miss_res))
         lev_col = int(top - (start_level + 1))          # column of the parent level in parchi
-        col = np.zeros(parchi.shape[0], dtype=np.int64)
-        for j, parent in enumerate(uniq):
-            col[parchi[:, lev_col] == parent] = base + 1 + j
+        pp_ = np.clip(np.searchsorted(uniq, parchi[:, lev_col]), 0, uniq.size - 1)
+        col = np.where(uniq[pp_] == parchi[:, lev_col], base + 1 + pp_, 0).astype(np.int64)
         parchi = np.column_stack([parchi, col])
         res_is_ref_l.append(0)
 
     res_is_ref = np.asarray(res_is_ref_l, dtype=np.int64)
-    parchi = np.unique(parchi, axis=0)
+    parchi = _unique_rows(parchi)
     return TreeResult(ix=np.concatenate(all_ix), block=np.concatenate(all_block), res=np.concatenate(all_res),
                       parchi_map=parchi, res_is_ref=res_is_ref, thresholds=thresholds_list)
 
@@ -268,11 +372,11 @@ def make_edges(parchimat: np.ndarray, non_empty_blocks: np.ndarray, res_is_ref: 
             cols = ref_cols[ref_cols < lev] if ref_cols.size > 0 else np.arange(lev)
             for c in cols:
                 sel = ok & (parchimat[:, c] > 0)
-                par_pairs.append(np.unique(np.column_stack([col[sel], parchimat[sel, c]]), axis=0))
+                par_pairs.append(_unique_rows(np.column_stack([col[sel], parchimat[sel, c]])))
         if res_is_ref[lev] == 1 and lev < L - 1:
             for c in range(lev + 1, L):
                 sel = ok & (parchimat[:, c] > 0)
-                pr = np.unique(np.column_stack([col[sel], parchimat[sel, c]]), axis=0)
+                pr = _unique_rows(np.column_stack([col[sel], parchimat[sel, c]]))
                 pr = pr[non_empty[pr[:, 1]]]
                 chi_pairs.append(pr)
 
@@ -280,7 +384,7 @@ def make_edges(parchimat: np.ndarray, non_empty_blocks: np.ndarray, res_is_ref: 
         ptr = np.zeros(n_blocks + 1, dtype=np.int64)
         if not pairs:
             return ptr, np.zeros(0, dtype=np.int64)
-        allp = np.unique(np.concatenate(pairs, axis=0), axis=0)    # sorted by (u, other): ascending lists
+        allp = _unique_rows(np.concatenate(pairs, axis=0))    # sorted by (u, other): ascending lists
         cnt = np.bincount(allp[:, 0] - 1, minlength=n_blocks)
         ptr[1:] = np.cumsum(cnt)
         return ptr, allp[:, 1] - 1
@@ -312,17 +416,17 @@ def make_edges_limited(parchimat: np.ndarray, non_empty_blocks: np.ndarray, res_
             cols = ref_cols[ref_cols < lev] if ref_cols.size > 0 else np.arange(lev)
             c = int(cols[-1])
             sel = ok & (parchimat[:, c] > 0)
-            par_pairs.append(np.unique(np.column_stack([col[sel], parchimat[sel, c]]), axis=0))
+            par_pairs.append(_unique_rows(np.column_stack([col[sel], parchimat[sel, c]])))
         if res_is_ref[lev] == 1 and lev < L - 1:
             sel = ok & (parchimat[:, lev + 1] > 0)
-            pr = np.unique(np.column_stack([col[sel], parchimat[sel, lev + 1]]), axis=0)
+            pr = _unique_rows(np.column_stack([col[sel], parchimat[sel, lev + 1]]))
             chi_pairs.append(pr[non_empty[pr[:, 1]]])
 
     def _to_lists(pairs):
         ptr = np.zeros(n_blocks + 1, dtype=np.int64)
         if not pairs:
             return ptr, np.zeros(0, dtype=np.int64)
-        allp = np.unique(np.concatenate(pairs, axis=0), axis=0)
+        allp = _unique_rows(np.concatenate(pairs, axis=0))
         cnt = np.bincount(allp[:, 0] - 1, minlength=n_blocks)
         ptr[1:] = np.cumsum(cnt)
         return ptr, allp[:, 1] - 1
@@ -374,7 +478,7 @@ def prepare(y: np.ndarray, coords: np.ndarray, mv_id: Optional[np.ndarray] = Non
             cell_size: int = 25, K: Optional[Sequence[int]] = None, start_level: int = 0,
             tree_depth: float = np.inf, last_not_reference: bool = True,
             cherrypick_same_margin: bool = True, cherrypick_group_locations: bool = True,
-            limited_tree: bool = False) -> Topology:
+            limited_tree: bool = False, mvbias: float = 0.0, device: Optional[int] = None) -> Topology:
     """Row sorting, tree, edges and indexing exactly as `spamtree()` hands them to C++ (spamtree_fit.R:196-324).
 
     ``y`` may contain NaN (= NA).  Returns arrays in the *sorted* row order (by coordinates, then original id).
@@ -392,7 +496,7 @@ def prepare(y: np.ndarray, coords: np.ndarray, mv_id: Optional[np.ndarray] = Non
     sort_ix = np.lexsort(keys)
     cs = coords[sort_ix]; ys = y[sort_ix]; ms = mv_id[sort_ix]
     tree = make_tree(cs, np.isfinite(ys), ms, axis_cell_size, K, start_level, tree_depth,
-                     last_not_reference, cherrypick_same_margin, cherrypick_group_locations)
+                     last_not_reference, cherrypick_same_margin, cherrypick_group_locations, mvbias, device)
     blocking = np.zeros(n, dtype=np.int64)
     res_row = np.zeros(n, dtype=np.int64)
     blocking[tree.ix] = tree.block
@@ -402,8 +506,7 @@ def prepare(y: np.ndarray, coords: np.ndarray, mv_id: Optional[np.ndarray] = Non
     n_blocks = int(blocking.max())
 
     # gix_block: index of the coordinate group inside its block (spamtree_fit.R:271-279)
-    _, gix = np.unique(cs, axis=0, return_inverse=True)
-    gix = gix.reshape(-1)
+    gix = _coord_groups(cs)
     gix_block = np.zeros(n, dtype=np.int64)
     o = np.lexsort((gix, blocking))
     bs, gs = blocking[o], gix[o]

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     syms = set()
-    for hdr in ("spamtree_hip.h", "spamtree_fit.h"):
+    for hdr in ("spamtree_hip.h", "spamtree_fit.h", "spamtree_tree.h"):
         txt = open(os.path.join(ROOT, "include", hdr)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         syms |= set(re.findall(r"\b((?:st|stm)_[a-z_0-9]+|spamtree_mv_mcmc_c)\s*\(", txt))
