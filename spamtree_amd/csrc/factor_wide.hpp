@@ -1,0 +1,347 @@
+// Included by spamtree_hip.hip after factor_big.hpp (needs FactorArgs, Blk, CovPar, cov_entry, d4, dma typedefs, chol helpers).
+#pragma once
+
+// Phase A for wide blocks / long chains (the default multivariate tree, config #4: 75-row blocks, chains up to 525 rows),
+// second generation: a workgroup factorises a SIBLING GROUP -- up to WG_MAXB consecutive blocks of one parent, N <= WG_MAXN
+// columns in all -- at once.  Siblings share their whole ancestor chain, so every 16-row sub-panel of the chain's inverse
+// Cholesky factor is staged (LDS-DMA) ONCE for all of them, and every wave has matrix work in both halves of a step:
+//   * V_sub = Linv_sub K (16 x N): the group's N / 16 column tiles are dealt over the 8 waves (k_factor_bigmfma has one
+//     block's 3-5 tiles: 3-5 busy waves); A from LDS, B straight from K in the workgroup's scratch slice (L2);
+//   * T[column][chain] += V_sub' Linv_sub with the accumulators in registers: wave w owns ONE chain tile per pass
+//     (kt = 8 pass + w) for all column tiles (<= WJT x 8 VGPRs); ceil(P / 128) passes, passes > 0 re-stage the panels that
+//     reach their chain tiles and read V back from the scratch slice;
+//   * epilogue per block of the group as in k_factor_bigmfma (Schur complement by MFMA from V, m x m factorisation in LDS,
+//     N = -Ri T by MFMA; diagonal only on non-reference levels).
+// Same arithmetic per block as k_factor_bigmfma up to the summation order inside the MFMA chains.
+#define WG_MAXB 8      // blocks per sibling group
+#define WG_MAXN 160    // columns per sibling group (WG_JT tiles of 16: the T accumulators of one chain tile, 8 VGPRs each, stay in registers)
+#define WG_JT 10
+#define WG_NT 512
+
+struct WideGrp { int first, count; };   // into the launch's block list: consecutive sibling blocks
+
+struct WideArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const int *list;        // device block ids of the level (this rank's run)
+  const WideGrp *groups;
+  int ngroups;
+  const double *cx, *cy;
+  const int *mv;
+  const double *w_in;
+  double *panels;
+  double *logdet_c, *loglik_c;
+  int *errflag;
+  double *scratch;
+  long long scratch_stride;
+  int maxP, maxN, maxM, maxMa, ldS;
+};
+
+template <int WJT>
+__global__ __launch_bounds__(WG_NT, 2) void k_factor_wide(WideArgs A, CovPar cp) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
+  __shared__ int s_bid[WG_MAXB], s_bm[WG_MAXB], s_bc[WG_MAXB + 1];
+  __shared__ int s_fail[WG_MAXB];
+  __shared__ double s_red[WG_NT / 64];
+  constexpr int NW = WG_NT / 64, LDV = 16 * WJT;
+
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int maxP = A.maxP, maxN = A.maxN, maxM = A.maxM;
+  const int ldS = A.ldS;
+  // LDS carve
+  double *sx = lds;
+  double *sy = sx + (maxP + maxN);
+  double *wv = sy + (maxP + maxN);
+  double *hv = wv + (maxP + maxN);     // maxN
+  double *rd = hv + maxN;              // maxN
+  double *stage = rd + maxN;           // 16 * ldS
+  double *zrow = stage + (size_t)16 * ldS;   // ldS zeros
+  double *VpL = zrow + ldS;            // 16 x LDV: the current sub-panel's V
+  const size_t work = max((size_t)17 * ldS + 16 * LDV, (size_t)2 * maxM * maxM + 64);   // the epilogue's R, Ri overlay stage .. VpL
+  int *smv = (int *)(stage + work);
+  double *KV, *Tt, *Vp;
+  {
+    double *g = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
+    KV = g; Tt = KV + (size_t)maxP * maxN; Vp = Tt + (size_t)maxP * maxN;   // Vp: maxMa x maxN
+  }
+  for (int gi = blockIdx.x; gi < A.ngroups; gi += gridDim.x) {
+    const WideGrp Gp = A.groups[gi];
+    const int nb = Gp.count;
+    __syncthreads();
+    for (int i = tid; i < (int)work; i += WG_NT) stage[i] = 0.0;   // stage, zero row, VpL (the previous epilogue wrote there)
+    const Blk B0 = A.blks[A.list[Gp.first]];
+    const int P = B0.P, J = B0.nanc;
+    if (tid < nb) { const int b = A.list[Gp.first + tid]; s_bid[tid] = b; s_bm[tid] = A.blks[b].m; s_fail[tid] = 0; }
+    if (tid >= 64 && tid < 64 + J) {
+      const int t = tid - 64;
+      const int a = A.anc_idx[B0.anc_ptr + t];
+      s_am[t] = A.blks[a].m; s_arow[t] = A.blks[a].row0; s_apan[t] = A.blks[a].chain_off;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
+      s_ao[J] = o;
+      int c = 0;
+      for (int i = 0; i < nb; ++i) { s_bc[i] = c; c += s_bm[i]; }
+      s_bc[nb] = c;
+    }
+    __syncthreads();
+    const int N = s_bc[nb];
+    const long long row0 = B0.row0;   // the group's columns are the rows row0 .. row0 + N - 1 (siblings are contiguous)
+    for (int t = 0; t < J; ++t) {
+      const long long r0 = s_arow[t];
+      const int oa = s_ao[t];
+      for (int i = tid; i < s_am[t]; i += WG_NT) { sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i]; }
+    }
+    for (int i = tid; i < N; i += WG_NT) { sx[P + i] = A.cx[row0 + i]; sy[P + i] = A.cy[row0 + i]; smv[P + i] = A.mv[row0 + i]; wv[P + i] = A.w_in[row0 + i]; }
+    __syncthreads();
+    // K_{pa, group}  (covariance_functions.cpp:95-111 / :213-286)
+    for (int idx = tid; idx < P * N; idx += WG_NT) {
+      const int k = idx / N, j = idx - k * N;
+      KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
+    }
+    __syncthreads();
+    // ---- the ancestor chain on the matrix cores
+    const int JT = (N + 15) >> 4;
+    const int nkt = (P + 15) >> 4;
+    const int npass = (nkt + NW - 1) / NW;
+    for (int pass = 0; pass < npass; ++pass) {
+      d4 tacc[WJT];
+#pragma unroll
+      for (int a = 0; a < WJT; ++a) tacc[a] = (d4){0.0, 0.0, 0.0, 0.0};
+      const int kt = pass * NW + wid;   // this wave's chain tile
+      for (int t = J - 1; t >= 0; --t) {
+        const int ma = s_am[t], oa = s_ao[t], Kb = oa + ma;
+        if (Kb <= 16 * NW * pass) continue;   // later passes: this ancestor does not reach their chain tiles (uniform)
+        const double *pa = A.panels + s_apan[t];
+        for (int r0 = 0; r0 < ma; r0 += 16) {
+          const int sr = min(16, ma - r0);
+          __syncthreads();   // everyone is done with the previous sub-panel's stage / VpL
+#pragma unroll
+          for (int rr = 0; rr < 16 / NW; ++rr) {
+            const int row = wid + NW * rr;
+            if (row < sr) {
+              const double *src = pa + (size_t)(r0 + row) * Kb;
+              for (int c = 0; 128 * c < Kb; ++c)
+                if (128 * c + 2 * lane < Kb)
+                  __builtin_amdgcn_global_load_lds((q_glb_void *)(src + 128 * c + 2 * lane), (q_lds_void *)(stage + (size_t)row * ldS + 128 * c), 16, 0, 0);
+            }
+          }
+          if (pass > 0) {   // V of this sub-panel comes back from the scratch slice (it replaced K's rows oa ..): overlaps the DMA
+            for (int idx = tid; idx < 16 * LDV; idx += WG_NT) {
+              const int i = idx / LDV, j = idx - i * LDV;
+              VpL[idx] = (i < sr && j < N) ? KV[(size_t)(oa + r0 + i) * N + j] : 0.0;
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int rr = 0; rr < 16 / NW; ++rr) {
+            const int row = wid + NW * rr;
+            if (lane < 20) stage[(size_t)row * ldS + Kb + lane] = 0.0;   // K-step / tile overshoot reads zeros
+          }
+          __syncthreads();
+          if (pass == 0) {
+            // V_sub = Linv_sub[:, 0:Kb] K[0:Kb, :]: column tiles jt = wid, wid + 8, ...
+            const int ns = (Kb + 3) >> 2;
+            const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + l4;
+            for (int jt = wid; jt < JT; jt += NW) {
+              const int j = jt * 16 + l15;
+              const bool jok = j < N;
+              const double *bp = KV + (size_t)l4 * N + min(j, N - 1);
+              d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+              int st = 0;
+              for (; st + 8 <= ns; st += 8) {   // eight B operands (L2) in flight per lane
+                double a4[8], b4[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                  const int k = 4 * (st + q) + l4;
+                  b4[q] = (jok && k < Kb) ? bp[(size_t)4 * (st + q) * N] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a4[q] = ap[4 * (st + q)];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
+              }
+              for (; st < ns; ++st) {
+                const int k = 4 * st + l4;
+                const double b1 = (jok && k < Kb) ? bp[(size_t)4 * st * N] : 0.0;
+                p = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * st], b1, p, 0, 0, 0);
+              }
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int i = l4 + 4 * r;
+                VpL[i * LDV + jt * 16 + l15] = p[r];
+                if (i < sr && jok) Vp[(size_t)(r0 + i) * N + j] = p[r];
+              }
+            }
+            __syncthreads();
+          }
+          // T[column tile a][chain tile kt] += V_sub' Linv_sub: the wave's chain-tile operands (B, from the staged rows) are
+          // read once per sub-panel and reused for every column tile of the group
+          if (kt * 16 < Kb) {
+            const int nst = (sr + 3) >> 2;
+            const double *b0 = stage + (size_t)l4 * ldS + kt * 16 + l15;
+            double bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = b0[(size_t)4 * r * ldS];
+            const double *vp = VpL + l4 * LDV + l15;
+#pragma unroll
+            for (int a = 0; a < WJT; ++a) {
+              if (a < JT) {
+                double av[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) av[r] = vp[4 * r * LDV + a * 16];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (r < nst) tacc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[r], tacc[a], 0, 0, 0);
+              }
+            }
+          }
+        }
+        if (pass == 0) {   // the ancestor's V rows replace the K rows they were computed from
+          __syncthreads();
+          for (int idx = tid; idx < ma * N; idx += WG_NT) KV[(size_t)oa * N + idx] = Vp[idx];
+        }
+      }
+      // this pass's T tiles -> the scratch slice (the epilogue reads T from there)
+      if (kt < nkt) {
+#pragma unroll
+        for (int a = 0; a < WJT; ++a) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = a * 16 + l4 + 4 * r, k = kt * 16 + l15;
+            if (j < N && k < P) Tt[(size_t)j * P + k] = tacc[a][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // hv = H w_pa  (wave per column of the group)
+    for (int j = wid; j < N; j += NW) {
+      double acc = 0.0;
+      for (int k = lane; k < P; k += 64) acc += Tt[(size_t)j * P + k] * wv[k];
+      acc = wave_sum(acc);
+      if (lane == 0) hv[j] = acc;
+    }
+    __syncthreads();
+
+    // ---- per block of the group: Schur complement, factorisation, output panel, scalars
+    for (int bi = 0; bi < nb; ++bi) {
+      const int b = s_bid[bi], m = s_bm[bi], cb = s_bc[bi];
+      const Blk B = A.blks[b];
+      const int MT = (m + 15) >> 4;
+      double *pu = A.panels + B.panel_off;
+      const int ld = B.ld;
+      double wcore_part = 0.0, logdet_part = 0.0;
+      __syncthreads();
+      if (B.isref) {
+        double *Rl = stage, *Ril = stage + (size_t)m * m;
+        {
+          const int ns = (P + 3) >> 2;
+          for (int e = wid; e < MT * (MT + 1) / 2; e += NW) {
+            int it = 0;
+            while ((it + 1) * (it + 2) / 2 <= e) ++it;
+            const int jt = e - it * (it + 1) / 2;
+            const int ci = it * 16 + l15, cj = jt * 16 + l15;
+            const double *ap = KV + (size_t)l4 * N + cb + min(ci, m - 1), *bp = KV + (size_t)l4 * N + cb + min(cj, m - 1);
+            d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+            int st = 0;
+            for (; st + 4 <= ns; st += 4) {
+              double a4[4], b4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const bool kok = 4 * (st + q) + l4 < P;
+                a4[q] = (kok && ci < m) ? ap[(size_t)4 * (st + q) * N] : 0.0;
+                b4[q] = (kok && cj < m) ? bp[(size_t)4 * (st + q) * N] : 0.0;
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
+            }
+            for (; st < ns; ++st) {
+              const bool kok = 4 * st + l4 < P;
+              const double a1 = (kok && ci < m) ? ap[(size_t)4 * st * N] : 0.0, b1 = (kok && cj < m) ? bp[(size_t)4 * st * N] : 0.0;
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+              if (i < m && j <= i)
+                Rl[i * m + j] = cov_entry(cp, sx[P + cb + i], sy[P + cb + i], smv[P + cb + i], sx[P + cb + j], sy[P + cb + j], smv[P + cb + j]) - c[r];
+            }
+          }
+        }
+        __syncthreads();
+        chol_lower_inplace(Rl, m, &s_fail[bi]);
+        tri_inverse_lower(Rl, Ril, m);
+        // panel_u = [ -Ri*T | Ri ]: tiles (row tile it, chain tile kc), A = -Ri from LDS, B = T from the scratch slice
+        {
+          for (int e = wid; e < MT * nkt; e += NW) {
+            const int it = e % MT, kc = e / MT;
+            const int ia = it * 16 + l15, kb = kc * 16 + l15;
+            const int njs = (min(m, it * 16 + 16) + 3) >> 2;
+            d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+            for (int st = 0; st < njs; ++st) {
+              const int j = 4 * st + l4;
+              const double a1 = (ia < m && j <= ia) ? -Ril[ia * m + j] : 0.0;
+              const double b1 = (j < m && kb < P) ? Tt[(size_t)(cb + j) * P + kb] : 0.0;
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = it * 16 + l4 + 4 * r;
+              if (i < m && kb < P) pu[(size_t)i * ld + kb] = c[r];
+            }
+          }
+        }
+        for (int idx = tid; idx < m * m; idx += WG_NT) {
+          const int i = idx / m, j = idx - i * m;
+          pu[(size_t)i * ld + P + j] = (j <= i) ? Ril[idx] : 0.0;
+        }
+        for (int i = tid; i < m; i += WG_NT) {   // e = Ri (w_u - H w_pa)
+          double acc = 0.0;
+          for (int j = 0; j <= i; ++j) acc += Ril[i * m + j] * (wv[P + cb + j] - hv[cb + j]);
+          wcore_part += acc * acc;
+          logdet_part += log(Ril[i * m + i]);
+        }
+      } else {
+        // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963)
+        double *part = stage;   // NW x 128
+        for (int i = tid & 63; i < m; i += 64) {
+          const int q = tid >> 6;
+          double acc = 0.0;
+          for (int k = q; k < P; k += NW) { const double v = KV[(size_t)k * N + cb + i]; acc += v * v; }
+          part[q * 128 + i] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < m; i += WG_NT) {
+          double acc = cov_entry(cp, sx[P + cb + i], sy[P + cb + i], smv[P + cb + i], sx[P + cb + i], sy[P + cb + i], smv[P + cb + i]);
+          for (int q = 0; q < NW; ++q) acc -= part[q * 128 + i];
+          if (!(acc > 0.0)) s_fail[bi] = 1;
+          const double r = 1.0 / sqrt(acc);
+          rd[i] = r;
+          pu[(size_t)i * ld + P] = r;
+          const double e = r * (wv[P + cb + i] - hv[cb + i]);
+          wcore_part += e * e;
+          logdet_part += log(r);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < m * P; idx += WG_NT) {
+          const int i = idx / P, k = idx - i * P;
+          pu[(size_t)i * ld + k] = -rd[i] * Tt[(size_t)(cb + i) * P + k];
+        }
+      }
+      const double wcore = block_sum(wcore_part, s_red);
+      const double logdet = block_sum(logdet_part, s_red);
+      __syncthreads();
+      if (tid == 0) {
+        A.logdet_c[b] = logdet;
+        A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
+        if (s_fail[bi]) atomicMin(A.errflag, B.level * 16 + (J == 0 ? 1 : (B.isref ? 2 : 3)));
+      }
+    }
+  }
+}

@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 
 #include "factor_quad.hpp"
 #include "factor_big.hpp"
+#include "factor_wide.hpp"
 
 struct SampleArgs {
   const Blk *blks;
@@ -2412,6 +2413,8 @@ struct LevelInfo {
   int ldN = 2, Mr4 = 4, Mrows = 1, av_dbl = 224;
   size_t lds_sfast = 0, lds_slean = 0;
   bool bigmfma = false;            // generic level whose phase A takes k_factor_bigmfma
+  int wide_first = 0, wide_count = 0, wide_maxN = 0;   // sibling groups of this rank's run (k_factor_wide); count 0: not used
+  size_t lds_wide = 0;
   int bm_ldS = 0;
   size_t lds_bigmfma = 0;
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
@@ -2438,6 +2441,9 @@ struct st_handle_s {
   DevBuf<Grp> d_grps;
   std::vector<Quad> quads;
   DevBuf<Quad> d_quads;
+  std::vector<WideGrp> wgrps;                 // sibling groups of the wide levels (k_factor_wide)
+  DevBuf<WideGrp> d_wgrps;
+  int wide_on = 1;                            // SPAMTREE_WIDE=0: k_factor_bigmfma (one block per workgroup) instead
   std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
   DevBuf<long long> d_gdesc;
   int gd_stride = 8;
@@ -2610,7 +2616,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_twin.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
+  h->d_twin.free(); h->d_wgrps.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_err2.free(); h->d_toplist.free();
   if (h->ev_top) (void)hipEventDestroy(h->ev_top);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
@@ -2851,6 +2857,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) == hipSuccess && v > 0) h->lds_limit = (size_t)v;
     if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
     h->quad_nu = 4;   // units per workgroup of k_factor_quad (2 per workgroup with two workgroups per CU measured slower)
+    { const char *e = getenv("SPAMTREE_WIDE"); h->wide_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
   }
   h->levels.resize(n_actual);
   auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
@@ -3010,6 +3017,42 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         }
         L.gown_lo = glo < ghi ? glo : 0; L.gown_n = glo < ghi ? ghi - glo : 0;
       }
+    }
+    // sibling groups for k_factor_wide (levels on the wide-block path): consecutive blocks of this rank's run with the same
+    // last parent (= the same chain; device order keeps siblings and their rows contiguous), at most WG_MAXB blocks and
+    // WG_MAXN columns per group
+    L.wide_first = (int)h->wgrps.size(); L.wide_count = 0; L.wide_maxN = 0;
+    // measured at config #4 (577^2 x 3 outcomes): the leaf level 32.7 -> 28.2 ms, the 75-column reference level 13.9 -> 15.1 ms
+    // (two blocks per group: more passes than staging saved), levels with fewer groups than CUs lose parallelism -- so only
+    // big non-reference levels take it (SPAMTREE_WIDE=2 forces it on every eligible level: tests)
+    if (L.bigmfma && h->wide_on && !h->limited && (h->wide_on == 2 || (!L.isref && L.own_n >= 2 * h->sm_count))) {
+      int k = L.own_lo;
+      const int kend = L.own_lo + L.own_n;
+      while (k < kend) {
+        const int b0 = h->lvl_list[L.first + k];
+        const Blk &B0 = h->blks[b0];
+        const int lastp = B0.nanc ? h->anc_idx[B0.anc_ptr + B0.nanc - 1] : -1;
+        WideGrp Gw; Gw.first = k - L.own_lo; Gw.count = 1;
+        int Ncols = B0.m;
+        while (k + Gw.count < kend && Gw.count < WG_MAXB) {
+          const int b1 = h->lvl_list[L.first + k + Gw.count];
+          const Blk &B1 = h->blks[b1];
+          const int lp1 = B1.nanc ? h->anc_idx[B1.anc_ptr + B1.nanc - 1] : -2;
+          if (lp1 != lastp || B1.nanc != B0.nanc || B1.isref != B0.isref || b1 != b0 + Gw.count || Ncols + B1.m > WG_MAXN ||
+              B1.row0 != B0.row0 + Ncols) break;
+          Ncols += B1.m; ++Gw.count;
+        }
+        L.wide_maxN = std::max(L.wide_maxN, Ncols);
+        h->wgrps.push_back(Gw);
+        ++L.wide_count;
+        k += Gw.count;
+      }
+      int ldS = L.maxP + 24;
+      while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
+      L.bm_ldS = ldS;
+      const size_t work = std::max((size_t)17 * ldS + 16 * 16 * WG_JT, (size_t)2 * L.maxM * L.maxM + 64);
+      L.lds_wide = ((size_t)3 * (L.maxP + L.wide_maxN) + 2 * (size_t)L.wide_maxN + work) * 8 + (size_t)((L.maxP + L.wide_maxN + 1) & ~1) * 4 + 64;
+      if (L.lds_wide > h->lds_limit) { h->wgrps.resize(L.wide_first); L.wide_count = 0; }
     }
     // quads for k_factor_quad: runs of up to quad_nu column groups of one rank that share their ancestor chain
     // (reference levels) or the chain without its last ancestor (leaf levels: cousins)
@@ -3208,6 +3251,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     CCHK(h->d_gdesc.upload(h->gdesc));
   }
   { std::vector<Quad> g = h->quads; if (g.empty()) g.push_back(Quad{0, 0, 0, 0}); CCHK(h->d_quads.upload(g)); }
+  { std::vector<WideGrp> g = h->wgrps; if (g.empty()) g.push_back(WideGrp{0, 0}); CCHK(h->d_wgrps.upload(g)); }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
   { std::vector<int> a = h->own_obs_list; if (a.empty()) a.push_back(0); CCHK(h->d_ownobs.upload(a)); }
@@ -3264,6 +3308,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     size_t need = 0;
     auto upd = [&](const LevelInfo &L) {
       if (L.big_factor || L.bigmfma) need = std::max(need, scratch_factor_doubles(L.maxP, L.maxM, L.maxMa));
+      if (L.wide_count > 0) need = std::max(need, (size_t)2 * L.maxP * L.wide_maxN + (size_t)L.maxMa * L.wide_maxN);
       if (L.big_sample) need = std::max(need, (size_t)L.maxM * L.maxM);
     };
     for (auto &L : h->levels) upd(L);
@@ -3284,6 +3329,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_factor_wide<WG_JT>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<5, 3, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<4, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -3591,6 +3637,14 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, st, F, cp);
+      } else if (L.bigmfma && h->factor_gen == 3 && L.wide_count > 0) {
+        WideArgs W;
+        std::memset(&W, 0, sizeof(W));
+        W.blks = h->d_blks.p; W.anc_idx = h->d_anc.p; W.list = h->d_lvl.p + L.first + L.own_lo; W.groups = h->d_wgrps.p + L.wide_first;
+        W.ngroups = L.wide_count; W.cx = h->d_cx.p; W.cy = h->d_cy.p; W.mv = h->d_mv.p; W.w_in = h->d_w.p; W.panels = h->d_panels[phys].p;
+        W.logdet_c = h->d_logdet[phys].p; W.loglik_c = h->d_loglik[phys].p; W.errflag = errflag; W.scratch = h->d_scratch.p;
+        W.scratch_stride = h->scratch_stride; W.maxP = L.maxP; W.maxN = L.wide_maxN; W.maxM = L.maxM; W.maxMa = L.maxMa; W.ldS = L.bm_ldS;
+        hipLaunchKernelGGL((k_factor_wide<WG_JT>), dim3(std::min(L.wide_count, h->sm_count)), dim3(WG_NT), L.lds_wide, st, W, cp);
       } else if (L.bigmfma && h->factor_gen == 3) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride; A.SR = L.bm_ldS;
         if (L.maxM <= 48) hipLaunchKernelGGL((k_factor_bigmfma<3, 5, 34>), dim3(std::min(A.nlist, h->sm_count)), dim3(BM_NT), L.lds_bigmfma, st, A, cp);
@@ -4265,7 +4319,7 @@ extern "C" int st_level_info(st_handle h, int32_t *n_levels, int32_t *kernel, in
     int k = L.big_factor ? ST_KERNEL_GENERIC_SCRATCH : ST_KERNEL_GENERIC_LDS;
     if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) k = ST_KERNEL_QUAD;
     else if (L.fast) k = ST_KERNEL_MFMA;
-    else if (L.bigmfma && h->factor_gen == 3) k = ST_KERNEL_BIGMFMA;
+    else if (L.bigmfma && h->factor_gen == 3) k = L.wide_count > 0 ? ST_KERNEL_WIDE : ST_KERNEL_BIGMFMA;
     if (kernel) kernel[g] = k;
     if (max_m) max_m[g] = L.maxM;
     if (max_P) max_P[g] = L.maxP;

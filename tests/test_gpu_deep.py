@@ -47,13 +47,18 @@ def compare_all(pb, expect):
     hm.close()
 
 
+@pytest.mark.parametrize("wide", ["0", "2"])
 @pytest.mark.parametrize("nx,leaf_inst", [(370, "<3,5,34>"), (400, "<4,5,34>")])
-def test_config4_chains_bigmfma_second_pass(nx, leaf_inst):
+def test_config4_chains_bigmfma_second_pass(nx, leaf_inst, wide, monkeypatch):
+    """wide = "2": the sibling-group kernel k_factor_wide forced onto every eligible level (by default only big non-reference
+    levels take it) -- chains of 450 / 525 rows take 4 / 5 passes of eight chain tiles; wide = "0": k_factor_bigmfma, one
+    block per workgroup, second pass beyond 384 rows."""
+    monkeypatch.setenv("SPAMTREE_WIDE", wide)
     coords, mv = strip_coords(nx, 10, 3)
     pb = make_problem(coords=coords, mv_id=mv, q=3, seed=3, K=(2, 1), tree_depth=7)
 
     def expect(info):
-        assert len(info) == 8 and all(L["kernel"] == "k_factor_bigmfma" for L in info[1:])
+        assert len(info) == 8 and all(L["kernel"] == ("k_factor_wide" if wide == "2" else "k_factor_bigmfma") for L in info[1:])
         # level 7 (index 6): the second pass needs more than 64 columns and more than 16 * 24 = 384 chain rows
         assert info[6]["max_m"] > 64 and info[6]["max_P"] == 450 and info[6]["max_P"] > 384
         assert info[7]["max_P"] == 525
