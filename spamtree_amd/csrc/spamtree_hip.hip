@@ -576,14 +576,10 @@ __device__ __forceinline__ double wave_allsum(double x);
 // the right-hand side rides along the elimination as one more column (forward substitution for free); the backward
 // substitution costs one wave sum per row.  No LDS traffic, no barriers inside.  m <= MM <= 32.  All 64 lanes must call.
 //   Sm: LDS, row stride CH_LD, lower triangle valid.  bm, zm, wout: LDS vectors (wout may alias bm or zm).
+// core: lane i holds row i of S in a[] (entries j <= i; the caller sets a[j] = (j == lane) for rows >= m and 0 above the
+// diagonal), c = b_i, zi = z_i; returns w_i (lanes >= m: unspecified)
 template <int MM>
-__device__ __forceinline__ void wave_chol_solve(const double *Sm, const double *bm, const double *zm, double *wout, int m, int *fail, int lane) {
-  double a[MM];
-  const bool row = lane < m;
-#pragma unroll
-  for (int j = 0; j < MM; ++j) a[j] = (row && j <= lane) ? Sm[min(lane, 31) * CH_LD + j] : (j == lane ? 1.0 : 0.0);
-  double c = row ? bm[min(lane, 31)] : 0.0;   // running right-hand side: ends as L_ii y_i
-  const double zi = row ? zm[min(lane, 31)] : 0.0;
+__device__ __forceinline__ double wave_chol_solve_core(double (&a)[MM], double c, const double zi, int m, int *fail, int lane) {
   double dd = 1.0;
   bool bad = false;
 #pragma unroll
@@ -615,6 +611,17 @@ __device__ __forceinline__ void wave_chol_solve(const double *Sm, const double *
       w = lane == k ? wk : w;
     }
   }
+  return w;
+}
+template <int MM>
+__device__ __forceinline__ void wave_chol_solve(const double *Sm, const double *bm, const double *zm, double *wout, int m, int *fail, int lane) {
+  double a[MM];
+  const bool row = lane < m;
+#pragma unroll
+  for (int j = 0; j < MM; ++j) a[j] = (row && j <= lane) ? Sm[min(lane, 31) * CH_LD + j] : (j == lane ? 1.0 : 0.0);
+  const double c = row ? bm[min(lane, 31)] : 0.0;   // running right-hand side: ends as L_ii y_i
+  const double zi = row ? zm[min(lane, 31)] : 0.0;
+  const double w = wave_chol_solve_core<MM>(a, c, zi, m, fail, lane);
   if (row) wout[lane] = w;
 }
 
@@ -1917,6 +1924,154 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Phase B, reference blocks of at most 27 rows, ONE BLOCK PER WAVE (four independent blocks per workgroup, no workgroup
+// barrier anywhere).  k_sample_lean gives a block 256 threads and eleven barriers for what is a chain of short dependent
+// steps (descriptor -> rows' data -> panel pass 1 -> children's records -> 25-pivot solve -> panel pass 2): a 55 us latency
+// chain per block with five of them in flight per CU.  Here a wave walks the same chain alone -- lane i owns row i: its
+// segment sums, row i of the posterior precision built straight into the registers the elimination works on
+// (wave_chol_solve_core), its draw -- with 11 KB of LDS, so twelve blocks are in flight per CU.  Same arithmetic and
+// summation orders as k_sample_lean (identical draws).  LDS operations of one wave execute in order: a wave-level
+// s_waitcnt separates the phases.
+// ---------------------------------------------------------------------------------------------------------------
+#define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_failw[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int gidx = blockIdx.x * (NT / 64) + wid;
+  if (gidx >= A.ngrp) return;   // no workgroup barrier below: a wave without a block simply leaves
+  double *base = lds + (size_t)wid * A.ldN;          // this wave's LDS region (A.ldN doubles)
+  long long *s_gd = (long long *)base;               // the block's descriptor
+  double *wv = base + A.gd_stride;                   // maxP + 32 : ancestors' w, then the block's new w
+  double *seg = wv + A.maxP + 32;                    // av_dbl : seg[t][r], later av[t][r]
+  double *tv = seg + A.av_dbl, *ev = tv + 32;
+  double *Rc = ev + 32;                              // Mrows x CH_LD: Ri
+  if (lane == 0) s_failw[wid] = 0;
+  for (int i = lane; i < A.gd_stride; i += 64) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
+  WSYNC();
+  auto slo = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)); };
+  auto shi = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v >> 32)); };
+  auto sll = [&](long long v) { return ((long long)shi(v) << 32) | (unsigned int)slo(v); };
+  const long long row0 = sll(s_gd[0]), acc_off = sll(s_gd[1]);
+  const int M = slo(s_gd[2]), P = shi(s_gd[2]), J = slo(s_gd[3]), level = shi(s_gd[4]);
+  const int nch = slo(s_gd[5]), acc_len = shi(s_gd[5]);
+  const long long *gb = s_gd + 8 + 4 * J;            // the block: panel offset, first row, ld
+  const long long bpan = sll(gb[0]);
+  const int bld = (int)sll(gb[2]);
+  const long long *coff = gb + 3;                    // message records of the direct children
+  auto am_of = [&](int t) { return (int)(s_gd[8 + 4 * t] & 0xffffffffLL); };
+  auto ao_of = [&](int t) { return (int)(s_gd[8 + 4 * t] >> 32); };
+  const bool row = lane < M;
+  const int li = min(lane, 31);
+  double tsq = 0.0, yx = 0.0, zc = 0.0;
+  if (row) { const long long r = row0 + lane; tsq = A.tausq_inv[A.mv[r]]; yx = A.y[r] - A.xb[r]; zc = A.z[r]; }
+  for (int k = lane; k < P; k += 64) {
+    int t = 0;
+    while (t + 1 < J && k >= ao_of(t + 1)) ++t;
+    wv[k] = A.w[s_gd[8 + 4 * t + 1] + (k - ao_of(t))];
+  }
+  for (int idx = lane; idx < M * M; idx += 64) {     // Ri -> LDS (the panel's last M columns)
+    const int i = idx / M, j = idx - i * M;
+    Rc[i * CH_LD + j] = (j <= i) ? A.panels[bpan + (size_t)i * bld + P + j] : 0.0;
+  }
+  WSYNC();
+  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
+  for (int idx = lane; idx < M * J; idx += 64) {
+    const int r = idx / J, t = idx - r * J;
+    const int ma = am_of(t), oa = ao_of(t);
+    const double *prow = A.panels + bpan + (size_t)r * bld + oa;
+    const double *wa = wv + oa;
+    double a = 0.0;
+    for (int j0 = 0; j0 < ma; j0 += 16) {
+      double x[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) x[jj] = (j0 + jj < ma) ? prow[j0 + jj] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+    }
+    seg[t * 32 + r] = a;
+  }
+  WSYNC();
+  double tvi = 0.0;
+  if (row) { for (int t = 0; t < J; ++t) tvi += seg[t * 32 + lane]; tv[lane] = tvi; }
+  WSYNC();
+  // ---- row `lane` of the posterior precision Ri'Ri + the children's Gram parts + tausq_inv, straight into registers
+  double a[27];
+#pragma unroll
+  for (int j = 0; j < 27; ++j) a[j] = 0.0;
+  double bv = 0.0;
+  for (int k = 0; k < M; ++k) {                      // Ri[k][i] = 0 for k < i: the leading terms add exact zeros
+    const double rk = Rc[k * CH_LD + li];
+    bv -= rk * tv[k];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) a[j] += rk * Rc[k * CH_LD + j];
+  }
+  for (int c = 0; c < nch; ++c) {                    // the children's records, fixed order
+    const double *rc = A.acc + coff[c] + acc_len;
+    double ch[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) ch[j] = (row && j <= lane) ? rc[li * M + j] : 0.0;
+    const double cv = row ? rc[M * M + li] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) a[j] += ch[j];
+    bv += cv;
+  }
+#pragma unroll
+  for (int j = 0; j < 27; ++j) {
+    if (j == lane) a[j] += tsq;
+    a[j] = (row && j <= lane) ? a[j] : (j == lane ? 1.0 : 0.0);
+  }
+  bv = row ? bv + tsq * yx : 0.0;
+  // ---- w_u = L^{-T} (L^{-1} b + z): elimination with the right-hand side riding along, backward substitution by wave sums
+  const double wnew = wave_chol_solve_core<27>(a, bv, zc, M, &s_failw[wid], lane);
+  if (row) { A.w[row0 + lane] = wnew; wv[P + lane] = wnew; }
+  WSYNC();
+  if (row) {
+    double e = tvi;
+    for (int j = 0; j <= lane; ++j) e += Rc[lane * CH_LD + j] * wv[P + j];
+    ev[lane] = e;
+  }
+  WSYNC();
+  for (int idx = lane; idx < J * 32; idx += 64) {    // av[t][r] = ev[r] - seg[t][r]
+    const int r = idx & 31;
+    seg[idx] = (r < M) ? ev[r] - seg[idx] : 0.0;
+  }
+  WSYNC();
+  // ---- pass 2: vector part of the records, -N_a' av_a + the children's
+  double *rec = A.acc + acc_off;
+  const int nfw = A.no_fwd ? 0 : nch;
+  for (int k = lane; k < P; k += 64) {
+    int t = 0;
+    while (t + 1 < J && k >= ao_of(t + 1)) ++t;
+    const int ma = am_of(t), i = k - ao_of(t);
+    const long long aoff = s_gd[8 + 4 * t + 3];
+    const double *avt = seg + t * 32;
+    double ch[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nfw) ? A.acc[coff[min(cc, max(nfw - 1, 0))] + aoff + ma * ma + i] : 0.0;
+    double acc = 0.0;
+    for (int r0 = 0; r0 < M; r0 += 8) {
+      double x[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < M) ? A.panels[bpan + (size_t)min(r0 + rr, M - 1) * bld + k] : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) acc -= x[rr] * avt[min(r0 + rr, 31)];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) acc += ch[cc];
+    for (int c0 = 4; c0 < nfw; c0 += 4) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nfw) ? A.acc[coff[min(c0 + cc, nfw - 1)] + aoff + ma * ma + i] : 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) acc += ch[cc];
+    }
+    rec[aoff + ma * ma + i] = acc;
+  }
+  WSYNC();
+  if (lane == 0 && s_failw[wid]) atomicMin(A.errflag, level * 16 + 10);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Phase B, fast path, leaf (non-reference) groups on sweeps that keep the cached Gram parts.  The rows of a leaf group
 // are independent given the ancestors (diagonal Ri), so a wave owns whole rows: lanes hold the row's columns (coalesced
 // loads, registers only), the per-ancestor segment sums come from masked butterfly reductions, the draw, the residual
@@ -2481,6 +2636,7 @@ struct st_handle_s {
   long long draws_cap = 0, n_draws = 0;
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
+  int sample_wave = 1;                        // reference blocks of <= 27 rows: one block per wave (SPAMTREE_SAMPLE_WAVE=0: k_sample_lean)
   int split_gram = 1;                         // sweeps that rebuild the Gram parts: k_gram + lean kernels (SPAMTREE_SPLIT_GRAM=0: k_sample_mfma)
   bool stats_valid = false;                   // d_stats matches the current w and XB
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
@@ -3334,6 +3490,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<4, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_sample_wave, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_marginal_invchol, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
     // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
@@ -3342,6 +3499,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     h->factor_gen = (e && e[0] == '1') ? 1 : 3;
     { const char *e2 = getenv("SPAMTREE_SAMPLE_LEAN"); h->sample_lean = (e2 && e2[0] == '0') ? 0 : 1; }
     { const char *e2 = getenv("SPAMTREE_SPLIT_GRAM"); h->split_gram = (e2 && e2[0] == '0') ? 0 : 1; }
+    { const char *e2 = getenv("SPAMTREE_SAMPLE_WAVE"); h->sample_wave = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }   // 2: every eligible level (tests)
   }
   {
     // k_factor_quad: static + dynamic LDS must fit; levels that do not fit (or are too small to fill the chip) keep k_factor_mfma
@@ -3940,7 +4098,12 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         }
         if (F.do_gram || !lean_ok) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
         else if (!L.isref) hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
-        else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
+        else if (h->sample_wave && L.maxM <= 27 && (h->sample_wave == 2 || L.gown_n >= 32 * h->sm_count)) {   // one block per wave: 10 % faster on a level
+          // that keeps every CU busy for many rounds (n = 1e6, level 7: 0.48 -> 0.43 ms), slower on latency-bound small levels: gd | wv | seg | tv, ev | Ri, per wave
+          const size_t per = (((size_t)h->gd_stride + L.maxP + 32 + L.av_dbl + 64 + (size_t)std::max(L.maxM, 1) * CH_LD + 1) & ~(size_t)1);
+          F.ldN = (int)per; F.Mrows = L.maxM;
+          hipLaunchKernelGGL(k_sample_wave, dim3((L.gown_n + NT / 64 - 1) / (NT / 64)), dim3(NT), per * 8 * (NT / 64), h->stream, F);
+        } else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
       } else if (L.big_sample) {
         A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
         hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);

@@ -207,6 +207,30 @@ def test_lean_sample_kernel_matches_staged_kernel(case, monkeypatch):
     assert relerr(ws[0][om.na_ix_all], om.w[om.na_ix_all]) <= REL
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[6], CASES[8], CASES[5]])
+def test_wave_sample_kernel_matches_lean_kernel_and_oracle(case, monkeypatch):
+    """k_sample_wave (one reference block per wave; by default only on levels of >= 32 x CUs blocks, forced here) against
+    k_sample_lean -- same arithmetic and summation orders: identical draws -- and the oracle, incl. a rebuild sweep (k_gram)."""
+    pb = make_problem(seed=52, **case)
+    rng = np.random.default_rng(4)
+    zs = [rng.standard_normal(pb["n"]) for _ in range(3)]
+    ws = []
+    for wave in ("2", "0"):
+        monkeypatch.setenv("SPAMTREE_SAMPLE_WAVE", wave)
+        hm = hip_model(pb, tausq=0.2)
+        assert hm.get_loglik_comps_w(0)
+        for z in zs:
+            hm.deal_with_w(z)
+        ws.append(hm.get_w().copy())
+        hm.close()
+    om = oracle_model(pb, tausq=0.2)
+    assert om.get_loglik_comps_w(om.param_data)
+    for z in zs:
+        om.gibbs_sample_w(z)
+    assert np.array_equal(ws[0], ws[1])
+    assert relerr(ws[0][om.na_ix_all], om.w[om.na_ix_all]) <= REL
+
+
 def test_cross_covariance_ag10_export():
     """man/CrossCovarianceAG10.Rd:72-93 inputs (q = 2) and a q = 3 parameter set, device vs oracle (itself pinned by mpmath)."""
     from oracle import spamtree_oracle as so
