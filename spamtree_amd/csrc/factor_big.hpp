@@ -13,6 +13,9 @@
 // M <= 80 columns, P <= 544 rows (host check); anything else stays on k_factor<true, MODE_FACTOR>.
 #define BM_MAXP 544
 #define BM_NT 512   // 8 waves: two per SIMD, so that one wave's LDS-DMA / L2 / LDS waits overlap the other's MFMAs
+#define BM_KS 4     // the V phase splits a sub-panel's K range (its chain columns) four ways: (column tile, K slice) items are
+                    // dealt over all 8 waves -- a block's 3-5 column tiles alone keep only 3-5 of them busy for the whole
+                    // dependent MFMA chain (stamps: 56 % / 32 % of the leaf / reference level at config #4)
 // BM_JT column tiles x BM_KTW chain tiles per wave in registers; BM_KTP <= 8 BM_KTW chain tiles per pass: <5, 3, 24> for
 // blocks up to 80 columns (two passes beyond 384 rows), <4, 5, 34> / <3, 5, 34> for blocks up to 64 / 48 columns (the
 // leaves of the default multivariate tree: one pass).
@@ -40,7 +43,8 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
   double *stage = rd + maxM;           // 16 * ldS (+ zrow + VpL >= 2 maxM^2 doubles: the epilogue factorises there)
   double *zrow = stage + (size_t)16 * ldS;   // ldS zeros
   double *VpL = zrow + ldS;            // 16 x 80: the current sub-panel's V
-  const size_t work = max((size_t)17 * ldS + 16 * 80, (size_t)2 * maxM * maxM + 64);   // the epilogue's R, Ri overlay stage .. VpL
+  double *red = VpL + 16 * 80;         // BM_KS x BM_JT x 256: the V phase's partial tiles (K range split over the waves)
+  const size_t work = max((size_t)17 * ldS + 16 * 80 + BM_KS * BM_JT * 256, (size_t)2 * maxM * maxM + 64);   // the epilogue's R, Ri overlay stage .. red
   int *smv = (int *)(stage + work);
   double *KV, *Tt, *Vp, *R, *Ri;
   {
@@ -48,10 +52,13 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
     KV = g; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
   }
   for (int i = tid; i < (int)work; i += BM_NT) stage[i] = 0.0;   // stage, zero row, VpL: never NaN garbage
+  STAMP_DECL
+  int st_level = 0;
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
     const int b = A.list[li];
     const Blk B = A.blks[b];
     const int m = B.m, P = B.P, J = B.nanc;
+    st_level = B.level;
     __syncthreads();
     for (int i = tid; i < ldS + 16 * 80; i += BM_NT) zrow[i] = 0.0;   // the previous block's epilogue wrote over the zero row and the V tile
     if (tid < J) {
@@ -80,12 +87,14 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
       sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
     }
     __syncthreads();
+    STAMP(0);
     // K_{pa,u}  (covariance_functions.cpp:95-111 / :213-286), T = 0
     for (int idx = tid; idx < P * m; idx += BM_NT) {
       const int k = idx / m, j = idx - k * m;
       KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
     }
     __syncthreads();
+    STAMP(1);
     // ---- the ancestor chain on the matrix cores
     const int JT = (m + 15) >> 4;
     const int npass = P > 16 * BM_KTP ? 2 : 1;
@@ -127,17 +136,21 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
             }
           }
           __syncthreads();
+          STAMP(2);
           if (pass == 0) {
-            // V_sub = Linv_sub[:, 0:Kb] K[0:Kb, :]: column tile jt = wid (+ 4)
+            // V_sub = Linv_sub[:, 0:Kb] K[0:Kb, :]: items (column tile jt, K slice ks), partial tiles summed through LDS
             const int ns = (Kb + 3) >> 2;
+            const int per = (ns + BM_KS - 1) / BM_KS;   // K-steps per slice
             const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + l4;
-            for (int jt = wid; jt < JT; jt += BM_NT / 64) {
+            for (int it = wid; it < JT * BM_KS; it += BM_NT / 64) {
+              const int jt = it / BM_KS, ks = it - jt * BM_KS;
+              const int s0 = ks * per, s1 = min(ns, s0 + per);
               const int j = jt * 16 + l15;
               const bool jok = j < m;
               const double *bp = KV + (size_t)l4 * m + min(j, m - 1);
               d4 p = (d4){0.0, 0.0, 0.0, 0.0};
-              int st = 0;
-              for (; st + 8 <= ns; st += 8) {   // eight B operands (L2) in flight per lane
+              int st = s0;
+              for (; st + 8 <= s1; st += 8) {   // eight B operands (L2) in flight per lane
                 double a4[8], b4[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -149,30 +162,27 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
 #pragma unroll
                 for (int q = 0; q < 8; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
               }
-              for (; st + 4 <= ns; st += 4) {
-                double a4[4], b4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  a4[q] = ap[4 * (st + q)];
-                  const int k = 4 * (st + q) + l4;
-                  b4[q] = (jok && k < Kb) ? bp[(size_t)4 * (st + q) * m] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) p = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], p, 0, 0, 0);
-              }
-              for (; st < ns; ++st) {
+              for (; st < s1; ++st) {
                 const int k = 4 * st + l4;
                 const double b1 = (jok && k < Kb) ? bp[(size_t)4 * st * m] : 0.0;
                 p = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * st], b1, p, 0, 0, 0);
               }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int i = l4 + 4 * r;
-                VpL[i * 80 + jt * 16 + l15] = p[r];
-                if (i < sr && jok) Vp[(size_t)(r0 + i) * m + j] = p[r];
-              }
+              double *rp = red + (size_t)(ks * BM_JT + jt) * 256 + lane;
+              rp[0] = p[0]; rp[64] = p[1]; rp[128] = p[2]; rp[192] = p[3];
             }
             __syncthreads();
+            // the slices' sum, in slice order: element (i = l4 + 4 r, j = jt * 16 + l15) of the sub-panel's V
+            for (int e = tid; e < JT * 256; e += BM_NT) {
+              const int jt = e >> 8, q = e & 255, r = q >> 6, ln = q & 63;
+              double v = red[(size_t)jt * 256 + q];
+#pragma unroll
+              for (int ks = 1; ks < BM_KS; ++ks) v += red[(size_t)(ks * BM_JT + jt) * 256 + q];
+              const int i = (ln >> 4) + 4 * r, j = jt * 16 + (ln & 15);
+              VpL[i * 80 + j] = v;
+              if (i < sr && j < m) Vp[(size_t)(r0 + i) * m + j] = v;
+            }
+            __syncthreads();
+            STAMP(3);
           }
           // T[column tile jt][chain tile kt] += V_sub' Linv_sub for this wave's chain tiles kt = kt0 + wid + 8 c.  The V
           // operands (all column tiles, all K-steps) are read once per sub-panel and reused for every chain tile.
@@ -203,9 +213,11 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
             }
           }
         }
+        STAMP(4);
         if (pass == 0) {   // the ancestor's V rows replace the K rows they were computed from
           __syncthreads();
           for (int idx = tid; idx < ma * m; idx += BM_NT) KV[(size_t)oa * m + idx] = Vp[idx];
+          STAMP(5);
         }
       }
       // this pass's T tiles -> the scratch slice (the epilogue reads T from there)
@@ -236,6 +248,7 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
       }
     }
     __syncthreads();
+    STAMP(6);
 
     double *pu = A.panels + B.panel_off;
     const int ld = B.ld;
@@ -280,8 +293,10 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
         }
       }
       __syncthreads();
+      STAMP(7);
       chol_lower_inplace(Rl, m, &s_fail);
       tri_inverse_lower(Rl, Ril, m);
+      STAMP(8);
       // panel_u = [ -Ri*T | Ri ]: tiles (row tile it, chain tile kt), A = -Ri from LDS, B = T from the scratch slice
       {
         const int nkt = (P + 15) >> 4;
@@ -345,12 +360,14 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
     const double wcore = block_sum(wcore_part, s_red);
     const double logdet = block_sum(logdet_part, s_red);
     __syncthreads();
+    STAMP(9);
     if (tid == 0) {
       A.logdet_c[b] = logdet;
       A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
       if (s_fail) atomicMin(A.errflag, B.level * 16 + (J == 0 ? 1 : (B.isref ? 2 : 3)));
     }
   }
+  STAMP_FLUSH_LEVEL(st_level);
 }
 
 

@@ -3123,7 +3123,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         int ldS = L.maxP + 24;
         while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
         L.bm_ldS = ldS;
-        const size_t work = std::max((size_t)17 * ldS + 16 * 80, (size_t)2 * L.maxM * L.maxM + 64);   // stage + zero row + V tile | R, Ri of the epilogue
+        const size_t work = std::max((size_t)17 * ldS + 16 * 80 + BM_KS * 5 * 256, (size_t)2 * L.maxM * L.maxM + 64);   // stage + zero row + V tile + partial V tiles | R, Ri of the epilogue
         L.lds_bigmfma = ((size_t)3 * (L.maxP + L.maxM) + 3 * (size_t)L.maxM + work) * 8 + (size_t)((L.maxP + L.maxM + 1) & ~1) * 4 + 64;
         L.bigmfma = L.lds_bigmfma <= h->lds_limit;
       }
