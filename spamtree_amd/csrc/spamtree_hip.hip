@@ -192,6 +192,37 @@ __device__ void tri_inverse_lower(const double *L, double *Ri, int m) {
   __syncthreads();
 }
 
+// Ri = chol(A)^{-1} for an m x m matrix in LDS (row-major, stride m, lower triangle referenced; A is destroyed), by the
+// whole workgroup with ONE barrier per pivot: the symmetric elimination of [A | I] (A = L~ D L~', row i of I becomes row i of
+// L~^{-1}), then Ri = D^{-1/2} L~^{-1} -- the scheme of wave_chol_eliminate for blocks too wide for one wave's registers
+// (75-row blocks of the default multivariate tree).  chol_lower_inplace + tri_inverse_lower cost three barriers per pivot
+// and then one THREAD per column of the inverse: 23-29 % of a reference level of config #4 (profiles/r02).
+// *fail set when a pivot is not > 0.  All threads of the block must call; Ri must not alias A.
+__device__ void block_chol_invert(double *A, double *Ri, int m, int *fail) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int idx = tid; idx < m * m; idx += nt) { const int i = idx / m, j = idx - i * m; Ri[idx] = (i == j) ? 1.0 : 0.0; }
+  __syncthreads();
+  const int tj = tid & 31, ti = tid >> 5, nti = nt >> 5;
+  for (int k = 0; k < m; ++k) {
+    const double d = A[k * m + k];
+    if (!(d > 0.0) && tid == 0) *fail = 1;
+    const double rd = 1.0 / d;
+    for (int i = k + 1 + ti; i < m; i += nti) {
+      const double f = -A[i * m + k] * rd;
+      for (int j = tj; j <= i; j += 32) {
+        if (j <= k) Ri[i * m + j] = fma(f, Ri[k * m + j], Ri[i * m + j]);      // row k of the identity part is final
+        else A[i * m + j] = fma(f, A[j * m + k], A[i * m + j]);                // A[k][j] = A[j][k]: column k is not written in this step
+      }
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < m * m; idx += nt) {
+    const int i = idx / m, j = idx - i * m;
+    if (j <= i) Ri[idx] *= rsqrt(A[i * m + i]);
+  }
+  __syncthreads();
+}
+
 // Philox4x32-10 (Salmon et al. 2011) -- same stream contract as oracle.StRng
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
                                               unsigned out[4]) {
