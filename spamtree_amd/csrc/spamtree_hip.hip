@@ -1156,6 +1156,7 @@ struct SampleArgs {
   int maxP, maxM, maxLd;
   int do_gram;
   int no_fwd;   // limited_tree: a block's record goes to its single parent only, nothing is forwarded from its children
+  int lds_sq;   // BIG: the posterior precision and its inverse Cholesky factor (2 maxM^2 doubles) live in LDS, after the vectors
   double tausq_inv[QMAX];
 };
 
@@ -1175,7 +1176,8 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   double *av = bv + maxM;              // maxM   per-ancestor temp
   double *seg = av + maxM;             // MAXJ * maxM: seg[t][r] = sum_j N[r][oa_t + j] w_a[j], later ev[r] - seg[t][r]
   double *Np = seg + (size_t)MAXJ * maxM;   // !BIG: maxM * maxLd panel copy
-  double *S = BIG ? (A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
+  double *S = BIG ? (A.lds_sq ? Np : A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
+  double *Li = S + (size_t)maxM * maxM;   // BIG with lds_sq only
 
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
     const int b = A.list[li];
@@ -1247,6 +1249,23 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         acc += A.tausq_inv[A.mv[r]] * (A.y[r] - A.xb[r]);
         bv[i] = acc;
       }
+      if (BIG && A.lds_sq) {
+        // w_u = Li' (Li Smu + z) with Li = chol(S)^{-1} from the one-barrier-per-pivot elimination: two matrix-vector
+        // products instead of a forward and a backward substitution of m barrier pairs each (wide blocks: m up to 80)
+        __syncthreads();
+        block_chol_invert(S, Li, m, &s_fail);
+        for (int i = tid; i < m; i += NT) {
+          double acc = A.z[B.row0 + i];
+          for (int j = 0; j <= i; ++j) acc += Li[i * m + j] * bv[j];
+          av[i] = acc;
+        }
+        __syncthreads();
+        for (int j = tid; j < m; j += NT) {
+          double acc = 0.0;
+          for (int i = j; i < m; ++i) acc += Li[i * m + j] * av[i];
+          bv[j] = acc;
+        }
+      } else {
       chol_lower_inplace(S, m, &s_fail);
       // w_u = L^{-T} (L^{-1} Smu + z)   (= Sigi_chol' (Sigi_chol Smu + z), :1086)
       for (int k = 0; k < m; ++k) {
@@ -1264,6 +1283,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         __syncthreads();
         if (tid == 0) bv[k] = xk;
         for (int i = tid; i < k; i += NT) bv[i] -= S[k * m + i] * xk;
+      }
       }
       __syncthreads();
       for (int i = tid; i < m; i += NT) {
@@ -2588,7 +2608,7 @@ struct LevelInfo {
   int first = 0, count = 0;   // into lvl_list
   int isref = 1;
   int maxP = 0, maxM = 0, maxMa = 0, maxLd = 0;
-  bool big_factor = false, big_sample = false;
+  bool big_factor = false, big_sample = false, sample_sq = false;   // sample_sq: k_sample<true> keeps S and chol(S)^-1 in LDS
   size_t lds_factor = 0, lds_sample = 0, lds_loglik = 0;
   double alg_bytes_A = 0, alg_bytes_B = 0, alg_bytes_C = 0, alg_bytes_msg = 0;
   double flops_A = 0, flops_B = 0, flops_C = 0;
@@ -2785,6 +2805,7 @@ static size_t lds_factor_bytes(int maxP, int maxM, int maxMa, int SR, bool big) 
 static size_t scratch_factor_doubles(int maxP, int maxM, int maxMa) {
   return (size_t)2 * maxP * maxM + (size_t)maxMa * maxM + (size_t)2 * maxM * maxM;
 }
+static size_t lds_sample_sq_bytes(int maxM) { return (size_t)2 * maxM * maxM * 8; }
 static size_t lds_sample_bytes(int maxP, int maxM, int maxLd, bool big) {
   size_t dbl = (size_t)(maxP + maxM) + 4 * (size_t)maxM + (size_t)MAXJ * maxM;   // ... + segment sums seg[t][r]
   if (!big) dbl += (size_t)maxM * maxLd + (size_t)maxM * maxM;
@@ -3074,7 +3095,15 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     if (L.big_factor) L.lds_factor = lds_factor_bytes(L.maxP, L.maxM, L.maxMa, 4, true);
     L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, false);
     L.big_sample = h->force_generic || L.lds_sample > h->lds_limit;
-    if (L.big_sample) L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, true);
+    if (L.big_sample) {
+      L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, true);
+      // measured at config #4: with 100 KB of LDS only one workgroup fits a CU, and on levels with more blocks than 2 x CUs the
+      // four co-resident workgroups of the scratch-arena path hide more latency (4.7 ms) than the fewer barriers save (7.8 ms);
+      // levels of at most 2 x CUs blocks are latency chains of single workgroups: 0.52 -> 0.41 ms
+      if (L.isref && L.count <= 2 * h->sm_count && L.lds_sample + lds_sample_sq_bytes(L.maxM) <= h->lds_limit) {
+        L.lds_sample += lds_sample_sq_bytes(L.maxM); L.sample_sq = true;
+      }
+    }
     L.lds_loglik = lds_loglik_bytes(L.maxP, L.maxM);
   };
   for (int g = 0; g < n_actual; ++g) {
@@ -4111,6 +4140,7 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
     A.do_gram = (h->gram_valid && h->cache_gram) ? 0 : 1;
     A.no_fwd = h->limited ? 1 : 0;
+    A.lds_sq = (L.big_sample && L.sample_sq) ? 1 : 0;
     {
       ProfScope ps(h, 1, h->n_actual_groups + g);   // per-level slots of phase B follow those of phase A
       if (L.fast) {
