@@ -226,8 +226,8 @@ class ExternalChain:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--side", type=int, default=1000, help="grid side; n = side^2 (1000 -> config #3, 316 -> #2)")
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--cell-size", type=int, default=25, help="knots per cell (config #5: 9)")
