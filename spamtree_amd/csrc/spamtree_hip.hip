@@ -3241,7 +3241,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     // measured at config #4 (577^2 x 3 outcomes): the leaf level 32.7 -> 28.2 ms, the 75-column reference level 13.9 -> 15.1 ms
     // (two blocks per group: more passes than staging saved), levels with fewer groups than CUs lose parallelism -- so only
     // big non-reference levels take it (SPAMTREE_WIDE=2 forces it on every eligible level: tests)
-    if (L.bigmfma && h->wide_on && !h->limited && (h->wide_on == 2 || (!L.isref && L.own_n >= 2 * h->sm_count))) {
+    if (L.bigmfma && h->wide_on && !h->limited && (h->wide_on == 2 || (!L.isref && L.count >= 2 * h->sm_count))) {   // L.count, not the rank's share: the two kernels round
+      // differently, and a level must take the same one on every rank of every world size (bit-identical sharded runs)
       int k = L.own_lo;
       const int kend = L.own_lo + L.own_n;
       while (k < kend) {
