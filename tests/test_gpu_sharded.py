@@ -16,13 +16,17 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("side,q,quad_min", [(120, 1, None), (48, 3, None), (120, 1, "1")])
-def test_sharded_equals_single_process_bitwise(side, q, quad_min, tmp_path, monkeypatch):
+@pytest.mark.parametrize("side,q,quad_min,env", [(120, 1, None, {}), (48, 3, None, {}), (120, 1, "1", {}),
+                                                 (48, 3, None, {"SPAMTREE_WIDE": "2"}),          # sibling-group kernel on every wide level
+                                                 (120, 1, "1", {"SPAMTREE_SAMPLE_WAVE": "2"})])  # one block per wave in the sweep
+def test_sharded_equals_single_process_bitwise(side, q, quad_min, env, tmp_path, monkeypatch):
     """quad_min = "1": even these small levels take k_factor_quad (SPAMTREE_QUAD_MIN, inherited by the spawned ranks),
     whose quads are cut at ownership boundaries and sized by the rank's share of the level (here forced: 4 units per
     workgroup in the single process, 2 with two ranks, 1 with three) -- the results must not depend on how they are cut."""
     if quad_min:
         monkeypatch.setenv("SPAMTREE_QUAD_MIN", quad_min)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     units = {1: "4", 2: "2", 3: "1", 4: None}     # None: the library's own choice for the rank's share of a level
     import torch.multiprocessing as mp
     from tests._sharded_worker import gpu_worker
