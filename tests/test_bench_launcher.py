@@ -38,3 +38,20 @@ def test_world_size_mismatch_is_refused():
     r = run(["--gpus", "4", "--launch-check"], env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0",
                                                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_workload_label_follows_the_arguments_and_host_is_described():
+    """VERDICT r1 weak #10: config.workload must name the configuration actually run; cpu_baseline carries the host CPU."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    wl = {"n": 99856}
+    for (side, q, cs, miss), tag in {(1000, 1, 25, ""): "config #3", (316, 1, 25, ""): "config #2", (577, 3, 25, ""): "config #4",
+                                     (1155, 3, 9, "0.1,0.3,0.5"): "config #5", (200, 2, 16, ""): "custom"}.items():
+        a = argparse.Namespace(side=side, q=q, cell_size=cs, missing=miss)
+        s = bench.workload_name(a, wl, 5461, 7, 1)
+        assert s.startswith(tag) and f"{side}^2" in s and f"cell_size={cs}" in s and (miss in s)
+    assert "sharded over 4 GPUs" in bench.workload_name(argparse.Namespace(side=1000, q=1, cell_size=25, missing=""), wl, 1, 1, 4)
+    h = bench.host_cpu()
+    assert set(h) >= {"model", "physical_cores", "logical_cpus"} and h["logical_cpus"] >= 1
+    assert bench.mem_available_gb() > 0.0
