@@ -3559,7 +3559,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     const char *e = getenv("SPAMTREE_FACTOR_KERNEL");
     h->factor_gen = (e && e[0] == '1') ? 1 : 3;
     { const char *e2 = getenv("SPAMTREE_SAMPLE_LEAN"); h->sample_lean = (e2 && e2[0] == '0') ? 0 : 1; }
-    { const char *e2 = getenv("SPAMTREE_SPLIT_GRAM"); h->split_gram = (e2 && e2[0] == '0') ? 0 : 1; }
+    { const char *e2 = getenv("SPAMTREE_SPLIT_GRAM"); h->split_gram = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }
     { const char *e2 = getenv("SPAMTREE_SAMPLE_WAVE"); h->sample_wave = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }   // 2: every eligible level (tests)
   }
   {
@@ -4154,7 +4154,10 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
         const bool lean_ok = h->sample_lean != 0 && !(!L.isref && L.maxP > 255);
-        if (F.do_gram && lean_ok && h->split_gram) {   // the theta-only Gram parts on their own (k_gram), then the lean sweep kernels
+        // the theta-only Gram parts on their own (k_gram), then the lean sweep kernels: pays on big reference levels (n = 1e6,
+        // level 7: 0.84 -> 0.72 ms averaged over a run's sweeps), loses on leaf levels and on smaller reference levels, where
+        // the staged Gram of k_sample_mfma is cheaper (SPAMTREE_SPLIT_GRAM=2: every level; records identical either way)
+        if (F.do_gram && lean_ok && h->split_gram && (h->split_gram == 2 || (L.isref && L.gown_n >= 32 * h->sm_count))) {
           hipLaunchKernelGGL(k_gram, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
           F.do_gram = 0;
         }

@@ -215,6 +215,7 @@ def test_wave_sample_kernel_matches_lean_kernel_and_oracle(case, monkeypatch):
     rng = np.random.default_rng(4)
     zs = [rng.standard_normal(pb["n"]) for _ in range(3)]
     ws = []
+    monkeypatch.setenv("SPAMTREE_SPLIT_GRAM", "2")            # k_gram on every level (default: big reference levels only)
     for wave in ("2", "0"):
         monkeypatch.setenv("SPAMTREE_SAMPLE_WAVE", wave)
         hm = hip_model(pb, tausq=0.2)
