@@ -50,6 +50,7 @@ struct QuadArgs {
 // Row stride (doubles) of the staged chain rows, a function of the instantiation only, so that every LDS operand address
 // of the main loop is ONE per-lane base register + an immediate offset: >= the longest chain (4 NKX) + 24 zero-filled
 // columns, >= 178 (the epilogue's per-unit overlay: Ri, R, T hand-over slots), and 2 x odd (conflict-free A-operand reads).
+constexpr int QUAD_LEAF_KH = 5;   // leaf levels: K-steps per pass of the covariance scratch (8 waves x 5 x 64 doubles behind the arena)
 __host__ __device__ constexpr int quad_lds_stride(int nkx) {
   int s = 4 * nkx + 24 > 178 ? 4 * nkx + 24 : 178;
   while ((s & 1) || ((s >> 1) & 1) == 0) ++s;
@@ -75,7 +76,10 @@ __device__ __forceinline__ void dma_row(const double *src, double *dst, int Kb, 
 template <int NU, int NKX, int NKT, bool ISREF, bool WCH = true>
 __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar cp) {
   constexpr int NTQ = 128 * NU, NW = 2 * NU;
-  constexpr int PMAX = 4 * NKX, KH = (NKX + 1) / 2;   // K-steps evaluated per pass through the arena
+  // covariance scratch ([KH][64] doubles per wave, lane-private slots): reference levels keep it in the SECOND staging buffer
+  // (4 passes), leaf levels behind the arena (KH = 5: 20 KB), so that the first panel rows can travel by LDS-DMA UNDER the
+  // covariance pass instead of after it
+  constexpr int PMAX = 4 * NKX, KH = ISREF ? (NKX + 3) / 4 : QUAD_LEAF_KH, NPASS = (NKX + KH - 1) / KH;
   static_assert(NKT * 16 >= PMAX, "T tiles must cover the chain");
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   constexpr int ldS = quad_lds_stride(NKX);   // == A.ldS (host)
   double *arena = lds;
   double *zrow = arena + (size_t)NU * 16 * ldS;   // a row of zeros
-  double *xch = zrow + ldS;                       // reference quads only: V tiles of the jt = 1 waves, [NU][2 tiles][256]
+  double *xch = zrow + ldS;                       // reference quads: V tiles of the jt = 1 waves, [NU][2 tiles][256]; leaf quads: the covariance scratch
 
   STAMP_DECL
   int qidx = blockIdx.x;
@@ -202,6 +206,35 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   STAMP(0);
   const int p_sr0 = pmu > 16 ? (pmu + 1) >> 1 : pmu;   // rows of the first private sub-panel
   const int p_Kb = Pc + pmu;
+  constexpr int RP = 32 / NW;   // staged rows per wave and step
+  const int nit = RFL(s_nit);
+  // step i of the shared chain covers chain rows [32 (nit-1-i), ...): its rows travel from global memory straight into LDS
+  auto issue = [&](int i, double *buf) {
+    const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
+#pragma unroll
+    for (int rr = 0; rr < RP; ++rr) {
+      const int row = wid + NW * rr;
+      if (row < sr) {
+        const int len = RFL(s_rlen[c0 + row]);
+        dma_row(A.panels + s_rsrc[c0 + row], buf + (size_t)row * ldS, len, lane, len > 128);
+      }
+    }
+  };
+  // private (last) ancestors, leaf quads: sub-panel sp of every unit side by side, unit u's rows at buf + (u * stride + row) * ldS
+  auto priv_rows = [&](int sp) { return sp == 0 ? p_sr0 : (pmu > 16 ? pmu - p_sr0 : 0); };
+  auto priv_issue = [&](int sp, int stride) {
+    const int r0 = sp == 0 ? 0 : p_sr0, sr = priv_rows(sp);
+    const double *src = A.panels + s_ppan[u] + (size_t)r0 * p_Kb;
+    double *buf = arena + (size_t)u * stride * ldS;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = jt + 2 * rr;
+      if (row < sr) dma_row(src + (size_t)row * p_Kb, buf + (size_t)row * ldS, p_Kb, lane, true);
+    }
+  };
+  // the first rows are requested NOW and land under the covariance pass (whose scratch lies elsewhere)
+  if constexpr (ISREF) { if (nit > 0) issue(0, arena); }
+  else { if (pmmax > 0) priv_issue(0, 16); }
 
   // ---- K_{pa,u}: every lane evaluates the B operands of its own K-steps, kx[st] = K[4 st + l4][column jt*16 + l15 of
   // unit u], in a rolled loop (one covariance body per pass) through lane-private LDS slots, then picks them up with
@@ -212,9 +245,9 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     const bool cok = jc < Mu;
     const double mx = s_colx[u][jc], my = s_coly[u][jc];
     const int mvj = s_colmv[u][jc];
-    double *kb = arena + (size_t)wid * (KH * 64) + lane;   // [KH][64] per wave; NW * KH * 64 <= NU * 16 * ldS (host)
+    double *kb = (ISREF ? arena + (size_t)32 * ldS : xch) + (size_t)wid * (KH * 64) + lane;   // [KH][64] per wave (sizes: host)
 #pragma unroll
-    for (int hpass = 0; hpass < 2; ++hpass) {
+    for (int hpass = 0; hpass < NPASS; ++hpass) {
       const int st0 = hpass * KH;
       if (4 * st0 < Pu) {
         if (cp.q == 1) {   // cexpcov, constants hoisted
@@ -256,7 +289,8 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       }
     }
   }
-  lds_barrier();   // the arena is handed over to the staging
+  // no barrier here: the scratch slots are lane-private, and the first DMA into their region (reference quads: step 1 into
+  // the second buffer) is requested after the first barrier below
   STAMP(1);
   d4 tacc[NKT];
 #pragma unroll
@@ -271,7 +305,9 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   // vmcnt, i.e. on the LDS-DMA of the next step too).  Reference units: the jt = 1 wave hands its V tile to its partner
   // through LDS slot `slot` of the unit (one workgroup barrier -- every wave takes it, with or without columns), and the
   // jt = 0 wave forms the Schur tile (1, 0) = V_1' V_0 from it and its own tile, still in registers.
-  auto tile = [&](const double *tg, int nk, int KbT, int slot) __attribute__((always_inline)) {
+  // rmask >= 0 (private sub-panels packed without padding rows): V rows >= rmask are forced to zero (what the tile holds there
+  // belongs to the next unit: finite, but not ours).
+  auto tile = [&](const double *tg, int nk, int KbT, int slot, int rmask) __attribute__((always_inline)) {
     d4 p = (d4){0.0, 0.0, 0.0, 0.0};
     if (wact) {
       const int ns = (KbT + 3) >> 2;
@@ -285,6 +321,10 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (4 * c + i < NKX) QMFMA(a[i], kx[4 * c + i], p);
+      }
+      if (rmask >= 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = (4 * r + l4 < rmask) ? p[r] : 0.0;
       }
     }
     if constexpr (ISREF) {
@@ -319,35 +359,36 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   // first tile -- shorter when the step straddles ancestors; columns up to Kb + 24 are zero beyond a row's own length).
   // Called by every wave of the workgroup (barriers inside for reference units); sr is the same for all of them.
   auto compute = [&](const double *stg, int sr, int Kb, int KbA) __attribute__((always_inline)) {
-    tile(stg, (min(sr, 16) + 3) >> 2, KbA, 0);
-    if (sr > 16) tile(stg + 16 * ldS, (sr - 16 + 3) >> 2, Kb, 1);
+    tile(stg, (min(sr, 16) + 3) >> 2, KbA, 0, -1);
+    if (sr > 16) tile(stg + 16 * ldS, (sr - 16 + 3) >> 2, Kb, 1, -1);
   };
 
-  // ---- private (last) ancestors: every unit's sub-panel staged side by side (LDS-DMA), all waves busy
+  // ---- private (last) ancestors (leaf quads): every unit's sub-panel staged side by side (LDS-DMA), all waves busy.
+  // Sub-panel 0 (16-row slots, the whole arena) was requested before the covariance pass.  Sub-panel 1, when it has <= 12
+  // rows per unit, is packed WITHOUT padding rows into rows [0, 48): rows [48, 64) then take the first step of the shared
+  // chain (<= 16 rows: 175 chain rows = 5 x 32 + 15), requested when the matrix cores start on sub-panel 1.
+  bool pf = false;   // the shared chain's first step sits at row 48 (workgroup-uniform)
   if constexpr (!ISREF) if (pmmax > 0) {
-    double *buf = arena + (size_t)u * 16 * ldS;
+    const int ts1 = pmmax > 16 ? pmmax >> 1 : 0;                      // rows of sub-panel 1, longest unit
+    const bool tight = ts1 > 0 && ts1 <= 12;
+    pf = tight && nit > 0 && Pc - 32 * (nit - 1) <= 16;
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp) {
       if (sp == 0 || pmmax > 16) {
-        const int r0 = sp == 0 ? 0 : p_sr0;
-        const int sr = sp == 0 ? p_sr0 : (pmu > 16 ? pmu - p_sr0 : 0);
-        const double *src = A.panels + s_ppan[u] + (size_t)r0 * p_Kb;
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          const int row = jt + 2 * rr;
-          if (row < sr) {
-            dma_row(src + (size_t)row * p_Kb, buf + (size_t)row * ldS, p_Kb, lane, true);
-          }
-        }
+        const int stride = (sp == 1 && tight) ? ts1 : 16;
+        const int sr = priv_rows(sp);
+        double *buf = arena + (size_t)u * stride * ldS;
+        if (sp == 1) priv_issue(1, stride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
           const int row = jt + 2 * rr;
           if (row < sr && lane < 24) buf[(size_t)row * ldS + p_Kb + lane] = 0.0;
-          if (row >= sr) for (int k = lane; k < p_Kb + 24; k += 64) buf[(size_t)row * ldS + k] = 0.0;   // absent rows of the tile
+          if (row >= sr && stride == 16) for (int k = lane; k < p_Kb + 24; k += 64) buf[(size_t)row * ldS + k] = 0.0;   // absent rows of the tile
         }
         lds_barrier();
-        if (sr > 0) compute(buf, sr, p_Kb, p_Kb);
+        if (sp == 1 && pf) issue(0, arena + (size_t)48 * ldS);
+        if (sr > 0) tile(buf, (sr + 3) >> 2, p_Kb, 0, sr);
         lds_barrier();
       }
     }
@@ -355,30 +396,17 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
 
   STAMP(2);
   // ---- the shared chain, last rows first, 32 rows of the concatenated chain per step (two 16-row MFMA tiles; the step
-  // that holds the chain's first rows may be shorter).  Rows travel from global memory straight into one of two LDS
+  // that holds the chain's last rows may be shorter).  Rows travel from global memory straight into one of two LDS
   // buffers (LDS-DMA, no registers): the next step is requested when the matrix cores start on the current one; one
   // LDS-only barrier per step.  Row c of the chain belongs to ancestor t (s_ao[t] <= c < s_ao[t+1]) and has s_ao[t+1]
   // entries; a step's row length Kb is that of its last row, shorter rows are zero-filled up to Kb + 24.
   {
-    constexpr int RP = 32 / NW;   // rows per wave
-    const int nit = RFL(s_nit);
-    auto issue = [&](int i, double *buf) {   // step i covers chain rows [32 (nit-1-i), ...)
-      const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
-#pragma unroll
-      for (int rr = 0; rr < RP; ++rr) {
-        const int row = wid + NW * rr;
-        if (row < sr) {
-          const int len = RFL(s_rlen[c0 + row]);
-          dma_row(A.panels + s_rsrc[c0 + row], buf + (size_t)row * ldS, len, lane, len > 128);
-        }
-      }
-    };
-    if (nit > 0) issue(0, arena);
-    int cur = 0;
+    if constexpr (!ISREF) { if (nit > 0 && !pf) issue(0, arena); }   // (reference quads: requested before the covariance pass)
+    int cur = pf ? 1 : 0;
     for (int i = 0; i < nit; ++i) {
       const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
       const int Kb = RFL(s_rlen[c0 + sr - 1]);
-      double *buf = arena + (size_t)cur * 32 * ldS;
+      double *buf = arena + (size_t)((pf && i == 0) ? 48 : cur * 32) * ldS;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current step have landed
 #pragma unroll
       for (int rr = 0; rr < RP; ++rr) {

@@ -3336,7 +3336,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       L.q_nkx = need <= 32 ? 32 : (need <= 38 ? 38 : (need <= 44 ? 44 : 50));
       const int ldS = quad_lds_stride(L.q_nkx);   // the kernel's compile-time row stride (>= maxP + 24)
       L.q_ldS = ldS;
-      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)h->quad_nu * 512 : 0)) * 8;
+      L.lds_quad = ((size_t)h->quad_nu * 16 * ldS + ldS + (L.isref ? (size_t)h->quad_nu * 512 : (size_t)2 * h->quad_nu * QUAD_LEAF_KH * 64)) * 8;   // arena, zero row, V exchange / covariance scratch
       int min_groups = 2 * h->sm_count;   // smaller levels do not fill the chip with quads: k_factor_mfma's 4x more workgroups win
       { const char *e = getenv("SPAMTREE_QUAD_MIN"); if (e) min_groups = atoi(e); }
       if (L.grp_count < 2 * nq_any || mixed || L.grp_count < min_groups) L.q_nkx = 0;   // mostly singletons: nothing to share
