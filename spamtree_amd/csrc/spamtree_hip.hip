@@ -1137,6 +1137,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 #include "factor_quad.hpp"
 #include "factor_big.hpp"
 #include "factor_wide.hpp"
+#include "factor_lchain.hpp"
 
 struct SampleArgs {
   const Blk *blks;
@@ -2623,6 +2624,7 @@ struct LevelInfo {
   size_t lds_wide = 0;
   int bm_ldS = 0;
   size_t lds_bigmfma = 0;
+  int lchain = 0;                  // non-reference level on k_factor_lchain<lchain> (0: not used)
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
   int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
@@ -2650,6 +2652,7 @@ struct st_handle_s {
   std::vector<WideGrp> wgrps;                 // sibling groups of the wide levels (k_factor_wide)
   DevBuf<WideGrp> d_wgrps;
   int wide_on = 1;                            // SPAMTREE_WIDE=0: k_factor_bigmfma (one block per workgroup) instead
+  int lchain_on = 1;                          // SPAMTREE_LCHAIN=0: non-reference long-chain levels stay on k_factor_wide / k_factor_bigmfma
   std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
   DevBuf<long long> d_gdesc;
   int gd_stride = 8;
@@ -3066,6 +3069,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     if (h->lds_limit > 160 * 1024) h->lds_limit = 160 * 1024;
     h->quad_nu = 4;   // units per workgroup of k_factor_quad (2 per workgroup with two workgroups per CU measured slower)
     { const char *e = getenv("SPAMTREE_WIDE"); h->wide_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
+    { const char *e = getenv("SPAMTREE_LCHAIN"); h->lchain_on = (e && e[0] == '0') ? 0 : 1; }
   }
   h->levels.resize(n_actual);
   auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
@@ -3186,6 +3190,13 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         const size_t work = std::max((size_t)17 * ldS + 16 * 80 + BM_KS * 5 * 256, (size_t)2 * L.maxM * L.maxM + 64);   // stage + zero row + V tile + partial V tiles | R, Ri of the epilogue
         L.lds_bigmfma = ((size_t)3 * (L.maxP + L.maxM) + 3 * (size_t)L.maxM + work) * 8 + (size_t)((L.maxP + L.maxM + 1) & ~1) * 4 + 64;
         L.bigmfma = L.lds_bigmfma <= h->lds_limit;
+        // non-reference blocks, <= 64 columns, every block behind at least one ancestor: k_factor_lchain (K in registers, the
+        // chain factor streamed through LDS twice); a property of the level, the same on every rank
+        if (L.bigmfma && h->lchain_on && !h->limited && !L.isref && L.maxM <= 64 && L.maxP <= 544) {
+          bool all_anc = true;
+          for (int b : list) all_anc = all_anc && h->blks[b].nanc >= 1 && !h->blks[b].isref;
+          if (all_anc) L.lchain = L.maxP <= 384 ? 96 : 136;
+        }
       }
     }
     if (L.lds_factor > h->lds_limit || L.lds_sample > h->lds_limit || L.lds_loglik > h->lds_limit)
@@ -3241,7 +3252,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     // measured at config #4 (577^2 x 3 outcomes): the leaf level 32.7 -> 28.2 ms, the 75-column reference level 13.9 -> 15.1 ms
     // (two blocks per group: more passes than staging saved), levels with fewer groups than CUs lose parallelism -- so only
     // big non-reference levels take it (SPAMTREE_WIDE=2 forces it on every eligible level: tests)
-    if (L.bigmfma && h->wide_on && !h->limited && (h->wide_on == 2 || (!L.isref && L.count >= 2 * h->sm_count))) {   // L.count, not the rank's share: the two kernels round
+    if (L.bigmfma && !L.lchain && h->wide_on && !h->limited && (h->wide_on == 2 || (!L.isref && L.count >= 2 * h->sm_count))) {   // L.count, not the rank's share: the two kernels round
       // differently, and a level must take the same one on every rank of every world size (bit-identical sharded runs)
       int k = L.own_lo;
       const int kend = L.own_lo + L.own_n;
@@ -3547,6 +3558,20 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_wide<WG_JT>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  {
+    // k_factor_lchain: static + dynamic LDS must fit one CU's 160 KB, else the level stays on the older kernels
+    hipFuncAttributes fa;
+    size_t st96 = 16 * 1024, st136 = 16 * 1024;
+    if (hipFuncGetAttributes(&fa, (const void *)k_factor_lchain<96>) == hipSuccess) st96 = fa.sharedSizeBytes;
+    if (hipFuncGetAttributes(&fa, (const void *)k_factor_lchain<136>) == hipSuccess) st136 = fa.sharedSizeBytes;
+    for (auto &L : h->levels) {
+      if (!L.lchain) continue;
+      const size_t need = lc_dyn_doubles(L.lchain) * 8 + (L.lchain == 96 ? st96 : st136);
+      if (need > 160 * 1024) L.lchain = 0;
+    }
+    (void)hipFuncSetAttribute((const void *)k_factor_lchain<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lc_dyn_doubles(96) * 8));
+    (void)hipFuncSetAttribute((const void *)k_factor_lchain<136>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lc_dyn_doubles(136) * 8));
+  }
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<5, 3, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<3, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_bigmfma<4, 5, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -3856,6 +3881,9 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         F.Pm4 = L.Pm4; F.ldKV = L.ldKV; F.ldS = L.ldS; F.SRm = L.SRm; F.stage_dbl = L.stage_dbl;
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, st, F, cp);
+      } else if (L.bigmfma && h->factor_gen == 3 && L.lchain) {
+        if (L.lchain == 96) hipLaunchKernelGGL((k_factor_lchain<96>), dim3(A.nlist), dim3(LC_NT), lc_dyn_doubles(96) * 8, st, A, cp);
+        else hipLaunchKernelGGL((k_factor_lchain<136>), dim3(A.nlist), dim3(LC_NT), lc_dyn_doubles(136) * 8, st, A, cp);
       } else if (L.bigmfma && h->factor_gen == 3 && L.wide_count > 0) {
         WideArgs W;
         std::memset(&W, 0, sizeof(W));
@@ -4547,7 +4575,7 @@ extern "C" int st_level_info(st_handle h, int32_t *n_levels, int32_t *kernel, in
     int k = L.big_factor ? ST_KERNEL_GENERIC_SCRATCH : ST_KERNEL_GENERIC_LDS;
     if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) k = ST_KERNEL_QUAD;
     else if (L.fast) k = ST_KERNEL_MFMA;
-    else if (L.bigmfma && h->factor_gen == 3) k = L.wide_count > 0 ? ST_KERNEL_WIDE : ST_KERNEL_BIGMFMA;
+    else if (L.bigmfma && h->factor_gen == 3) k = L.lchain ? ST_KERNEL_LCHAIN : (L.wide_count > 0 ? ST_KERNEL_WIDE : ST_KERNEL_BIGMFMA);
     if (kernel) kernel[g] = k;
     if (max_m) max_m[g] = L.maxM;
     if (max_P) max_P[g] = L.maxP;

@@ -3,7 +3,8 @@ in about a minute: a thin strip split along one axis only (K = (2, 1)) gives a n
 
   * #4 (q = 3, default cell size: 75-row blocks): reference level 7 has P = 450 > 384 chain rows with m = 75 > 64 columns
     -> k_factor_bigmfma<5,3,24> takes its SECOND pass over the chain (spamtree_amd/csrc/factor_big.hpp, `pass == 1`);
-    the leaf level below has P = 525 -> <3,5,34> (m <= 48) or <4,5,34> (m <= 64).
+    the leaf level below has P = 525 -> k_factor_lchain<136> (K in registers, the chain factor streamed twice; default), or
+    with SPAMTREE_LCHAIN=0 k_factor_bigmfma<3,5,34> (m <= 48) / <4,5,34> (m <= 64) / k_factor_wide.
   * #5 (q = 3, cell_size = 9: 27-row blocks): levels with chains of 216 and 243 rows exceed k_factor_quad's 200-row register
     budget and take k_factor_mfma (chains 201-256).
 Reference: /root/reference/src/spamtree_model.cpp:880-922 (reference child branch), :923-963 (non-reference rows).
@@ -47,18 +48,21 @@ def compare_all(pb, expect):
     hm.close()
 
 
-@pytest.mark.parametrize("wide", ["0", "2"])
+@pytest.mark.parametrize("wide,lchain", [("0", "0"), ("2", "0"), ("0", "1")])
 @pytest.mark.parametrize("nx,leaf_inst", [(370, "<3,5,34>"), (400, "<4,5,34>")])
-def test_config4_chains_bigmfma_second_pass(nx, leaf_inst, wide, monkeypatch):
+def test_config4_chains_bigmfma_second_pass(nx, leaf_inst, wide, lchain, monkeypatch):
     """wide = "2": the sibling-group kernel k_factor_wide forced onto every eligible level (by default only big non-reference
     levels take it) -- chains of 450 / 525 rows take 4 / 5 passes of eight chain tiles; wide = "0": k_factor_bigmfma, one
     block per workgroup, second pass beyond 384 rows."""
     monkeypatch.setenv("SPAMTREE_WIDE", wide)
+    monkeypatch.setenv("SPAMTREE_LCHAIN", lchain)   # "1" (the default): the leaf level on k_factor_lchain
     coords, mv = strip_coords(nx, 10, 3)
     pb = make_problem(coords=coords, mv_id=mv, q=3, seed=3, K=(2, 1), tree_depth=7)
 
     def expect(info):
-        assert len(info) == 8 and all(L["kernel"] == ("k_factor_wide" if wide == "2" else "k_factor_bigmfma") for L in info[1:])
+        older = "k_factor_wide" if wide == "2" else "k_factor_bigmfma"
+        assert len(info) == 8 and all(L["kernel"] == older for L in info[1:7])
+        assert info[7]["kernel"] == ("k_factor_lchain" if lchain == "1" else older)
         # level 7 (index 6): the second pass needs more than 64 columns and more than 16 * 24 = 384 chain rows
         assert info[6]["max_m"] > 64 and info[6]["max_P"] == 450 and info[6]["max_P"] > 384
         assert info[7]["max_P"] == 525
