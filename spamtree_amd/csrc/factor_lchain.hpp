@@ -30,6 +30,21 @@ __host__ __device__ constexpr size_t lc_dyn_doubles(int nkx) {   // dynamic LDS:
   return a > b ? a : b;
 }
 
+// cov_entry with the per-pair constants in LDS (tab: rate | amp | amp2 | phi, QMAX^2 / QMAX entries each).  MV: branch-free
+// multivariate form (the second exponential is always evaluated and enters with amplitude amp2 = 0 where the reference has
+// no such term: the same value) so that several independent evaluations can be interleaved; !MV: cexpcov.
+template <bool MV>
+__device__ __forceinline__ double lc_cov(const double *tab, int q, double s2, double nphi, double xi, double yi, int vi, double xj, double yj, int vj) {
+  const double dx = xi - xj, dy = yi - yj;
+  const double h = cov_sqrt(dx * dx + dy * dy);
+  if constexpr (!MV) return s2 * cov_exp(nphi * h);
+  const int ij = vi * q + vj;
+  const double r = tab[QMAX * QMAX + ij] * cov_exp(-tab[ij] * h);
+  const double a2 = tab[2 * QMAX * QMAX + ij];
+  const double e2 = cov_exp(-tab[3 * QMAX * QMAX + vi] * h);
+  return a2 != 0.0 ? fma(a2, e2, r) : r;   // (a select, not a branch; r + a2 e2 rounds as the reference's sum does)
+}
+
 template <int NKX>
 __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp) {
   constexpr int PMAX = 4 * NKX, NTMAX = (PMAX + 15) / 16, ldS = lc_lds_stride(NKX);
@@ -45,6 +60,9 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   __shared__ long long s_rsrc[PMAX];   // chain row c: where it starts in the panel arena ...
   __shared__ int s_rlen[PMAX];         // ... and its length (entries up to the end of its own ancestor's rows)
   __shared__ double s_e2[64], s_lg[64];
+  __shared__ double s_cpt[3 * QMAX * QMAX + QMAX];   // rate, amp, amp2 per outcome pair, phi per outcome: the covariance pass reads
+                                                     // them from LDS (as kernel arguments indexed per lane they are global loads,
+                                                     // one dependent round trip per entry with a single wave per SIMD)
   __shared__ int s_fail;
 
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
@@ -65,6 +83,11 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
     s_am[tid] = A.blks[a].m; s_arow[tid] = A.blks[a].row0; s_apan[tid] = A.blks[a].chain_off;
   }
   if (tid == 0) s_fail = 0;
+  for (int i = tid; i < 3 * QMAX * QMAX + QMAX; i += LC_NT) {
+    const int a = i / (QMAX * QMAX), ij = i - a * (QMAX * QMAX);
+    s_cpt[i] = a == 0 ? cp.rate[ij] : (a == 1 ? cp.amp[ij] : (a == 2 ? cp.amp2[ij] : cp.phi[ij]));
+  }
+  STAMP_DECL
   __syncthreads();
   if (tid == 0) {
     int o = 0;
@@ -85,22 +108,37 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   }
   __syncthreads();
 
-  // phase-1 staging: tile r = chain rows [16 r, 16 r + 16); wave w moves rows w, w + 4, w + 8, w + 12 (128 doubles per piece)
+  // phase-1 staging: tile r = chain rows [16 r, 16 r + 16), moved in pieces of 128 doubles.
+  // One address and one LDS base (M0) per row: the pieces differ by the instruction's immediate offset, which advances the
+  // global and the LDS address alike.  Whole pieces are fetched (up to 127 doubles past the row's end: its successor in the
+  // arena; the padding pass wipes what the tile can read of them) -- only a fifth piece is cut at the row's end, because it
+  // would run into the next staged row.
+  // Who stages: a block of <= 48 columns leaves waves without columns -- THEY move the data (loader waves: requests, landing
+  // wait, padding), the column waves only meet them at the barrier; a CU's LDS-DMA path takes about 23 B per cycle, and a wave
+  // that requests blocks on it: 14 % of a column wave's time when everybody requests.  With four column waves everybody
+  // stages a quarter, as before.
+  const int JTb = (m + 15) >> 4;
+  const int nload = JTb < 4 ? 4 - JTb : 4, lidx = JTb < 4 ? wid - JTb : wid;
+  const bool isload = lidx >= 0;
   auto issue1 = [&](int r, double *buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = wid + 4 * j, c = 16 * r + row;
-      if (c < P) {
-        const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
-        const double *src = A.panels + s_rsrc[c];
-        double *dst = buf + (size_t)row * ldS;
-        for (int pc = 0; 128 * pc < len; ++pc)
-          if (128 * pc + 2 * lane < len)
-            __builtin_amdgcn_global_load_lds((q_glb_void *)(src + 128 * pc + 2 * lane), (q_lds_void *)(dst + 128 * pc), 16, 0, 0);
+    for (int row = lidx; row < 16; row += nload) {
+      const int c = min(16 * r + row, P - 1);   // rows beyond the chain (last tile): any row, zero-filled afterwards
+      const int ln = min(__builtin_amdgcn_readfirstlane(s_rlen[c]), 16 * (r + 1));   // the tile reads columns < 16 (r + 1) only
+      const double *srow = A.panels + s_rsrc[c] + 2 * lane;
+      q_lds_void *dst = (q_lds_void *)(buf + (size_t)row * ldS);
+      q_glb_void *sp = (q_glb_void *)srow;
+      __builtin_amdgcn_global_load_lds(sp, dst, 16, 0, 0);
+      if (ln > 128) __builtin_amdgcn_global_load_lds(sp, dst, 16, 1024, 0);
+      if (ln > 256) __builtin_amdgcn_global_load_lds(sp, dst, 16, 2048, 0);
+      if (ln > 384) __builtin_amdgcn_global_load_lds(sp, dst, 16, 3072, 0);
+      if (ln > 512) {
+        if (512 + 2 * lane < ln)
+          __builtin_amdgcn_global_load_lds((q_glb_void *)(srow + 512), (q_lds_void *)(buf + (size_t)row * ldS + 512), 16, 0, 0);
       }
     }
   };
-  issue1(NTL - 1, lds);   // lands under the covariance pass
+  STAMP(0);
+  if (isload) issue1(NTL - 1, lds);   // lands under the covariance pass
 
   // ---- K_{pa,u}: kx[st] = K[4 st + l4][column 16 wid + l15]  (covariance_functions.cpp:95-111 / :213-286), rolled loop
   // through lane-private LDS slots, picked up with static register indices
@@ -111,19 +149,28 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   const double mx = A.cx[jrow], my = A.cy[jrow], wj = A.w_in[jrow];
   const int mvj = A.mv[jrow];
   double kx[NKX];
+  const int qn = cp.q;
+  const double s2 = cp.ai1[0], nphi = -cp.tmv[0];
   {
     double *kb = sy + PMAX + (PMAX + 1) / 2 + 2 + (size_t)wid * (KH * 64) + lane;
 #pragma unroll
     for (int hp = 0; hp < NPASS; ++hp) {
       const int st0 = hp * KH;
       if (4 * st0 < P && wact) {
-#pragma unroll 1
-        for (int i = 0; i < KH; ++i) {
-          const int k = 4 * (st0 + i) + l4;
-          double v = 0.0;
-          if (cok && k < P) v = cov_entry(cp, sx[k], sy[k], smv[k], mx, my, mvj);
-          kb[i * 64] = v;
-        }
+        // four independent chains per trip: one wave per SIMD has nobody else to hide FP64 latency
+#define LC_COVLOOP(MV_)                                                                                         \
+  _Pragma("unroll 1") for (int i = 0; i < KH; i += 4) {                                                         \
+    double v[4];                                                                                                \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                             \
+      const int k = 4 * (st0 + i + e) + l4, kc = min(k, PMAX - 1);                                              \
+      const double c0 = lc_cov<MV_>(s_cpt, qn, s2, nphi, sx[kc], sy[kc], smv[kc], mx, my, mvj);                 \
+      v[e] = (cok && k < P) ? c0 : 0.0;                                                                         \
+    }                                                                                                           \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                               \
+      if (i + e < KH) kb[(i + e) * 64] = v[e];                                                                  \
+  }
+        if (qn == 1) { LC_COVLOOP(false) } else { LC_COVLOOP(true) }
+#undef LC_COVLOOP
 #pragma unroll
         for (int i = 0; i < KH; ++i)
           if (st0 + i < NKX) kx[st0 + i] = kb[i * 64];
@@ -135,6 +182,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
     }
   }
 
+  STAMP(1);
 #define LCMFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0)
   // ---- phase 1: V_r = Linv[r, 0 .. r] K, last tile first; V_r replaces kx[4 r .. 4 r + 3]
   double dacc = 0.0;   // sum_k V[k][column l15]^2 over this lane's rows
@@ -144,20 +192,24 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
     for (int r = NTMAX - 1; r >= 0; --r) {
       if (r < NTL) {   // workgroup-uniform
         double *buf = lds + (size_t)cur * B1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile r have landed
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = wid + 4 * j, c = 16 * r + row;
-          if (c < P) {
-            const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
-            // the tile reads columns < 16 (r + 1) only; zero from the row's own end (also wipes the DMA's odd-length overshoot)
-            if (len + lane < 16 * (r + 1)) buf[(size_t)row * ldS + len + lane] = 0.0;
-          } else {
-            for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;   // rows beyond the chain (last tile)
+        if (isload) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile r have landed
+          for (int row = lidx; row < 16; row += nload) {
+            const int c = 16 * r + row;
+            if (c < P) {
+              const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
+              // the tile reads columns < 16 (r + 1) only; zero from the row's own end (what was fetched past it)
+              if (len + lane < 16 * (r + 1)) buf[(size_t)row * ldS + len + lane] = 0.0;
+            } else {
+              for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;   // rows beyond the chain (last tile)
+            }
           }
         }
+        STAMP(2);
         lds_barrier();
-        if (r > 0) issue1(r - 1, lds + (size_t)(cur ^ 1) * B1);
+        STAMP(3);
+        if (r > 0 && isload) issue1(r - 1, lds + (size_t)(cur ^ 1) * B1);
+        STAMP(4);
         if (wact) {
           d4 p = (d4){0.0, 0.0, 0.0, 0.0};
           const double *ap = buf + l15 * ldS + l4;
@@ -169,11 +221,13 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
           for (int q = 0; q < 4; ++q)
             if (4 * r + q < NKX) kx[4 * r + q] = p[q];
         }
+        STAMP(5);
         cur ^= 1;
       }
     }
   }
   lds_barrier();   // phase 2 reuses the buffers
+  STAMP(6);
 
   // ---- r_j = 1 / sqrt(K_jj - sum_k V_kj^2)  (spamtree_model.cpp:944-951)
   double rj = 0.0;
@@ -182,7 +236,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
     dsum += __shfl_xor(dsum, 16, 64);
     dsum += __shfl_xor(dsum, 32, 64);
     if (cok) {
-      const double d = cov_entry(cp, mx, my, mvj, mx, my, mvj) - dsum;
+      const double d = (qn == 1 ? lc_cov<false>(s_cpt, qn, s2, nphi, mx, my, mvj, mx, my, mvj) : lc_cov<true>(s_cpt, qn, s2, nphi, mx, my, mvj, mx, my, mvj)) - dsum;
       if (!(d > 0.0)) s_fail = 1;
       rj = 1.0 / sqrt(d);
     }
@@ -193,48 +247,75 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
 
   // ---- phase 2: T[:, kt] = sum_{r >= kt} V_r' Linv[r, kt]; column block kt of Linv = chain rows [16 kt, P) x 16 columns,
   // row c at offset c * 16 of the buffer (static operand offsets); one LDS-DMA instruction moves 8 rows (8 lanes x 16 B each)
-  auto issue2 = [&](int kt, double *buf) {
-    const int g0 = 2 * kt, g1 = (P + 7) >> 3;   // groups of 8 rows; group g goes to wave g & 3
-    for (int g = g0 + ((wid - g0) & 3); g < g1; g += 4) {
-      const int c = 8 * g + (lane >> 3);
-      if (c < P) {
-        const double *src = A.panels + s_rsrc[c] + 16 * kt + 2 * (lane & 7);
-        __builtin_amdgcn_global_load_lds((q_glb_void *)src, (q_lds_void *)(buf + (size_t)g * 128), 16, 0, 0);
-      }
+  auto issue2 = [&](int kt, double *buf) {   // 8-row group g belongs to loader g % nload
+    const int g1 = (P + 7) >> 3, g0 = 2 * kt;
+    const int koff = 16 * kt + 2 * (lane & 7);
+    int g = g0 + lidx - (g0 % nload);
+    if (g < g0) g += nload;
+    for (; g < g1; g += nload) {   // rows beyond the chain: any row (their V rows are zero)
+      const double *rp = A.panels + s_rsrc[min(8 * g + (lane >> 3), P - 1)] + koff;
+      __builtin_amdgcn_global_load_lds((q_glb_void *)rp, (q_lds_void *)(buf + (size_t)g * 128), 16, 0, 0);
     }
   };
   double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;   // hv = T w_pa for columns 4 q + l4, this lane's chain columns
   {
     double *pu = A.panels + B.panel_off;
     const int ld = B.ld;
-    issue2(0, lds);
+    if (isload) issue2(0, lds);
     int cur = 0;
     for (int kt = 0; kt < NTL; ++kt) {
       double *buf = lds + (size_t)cur * B2;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // the diagonal tile's entries above the diagonal are structural zeros, but rows that END inside this column block were
-      // fetched past their end: wipe (the owner of the 8-row group does it, after its own data has landed)
+      if (isload) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the diagonal tile's entries above the diagonal are structural zeros, but rows that END inside this column block were
+        // fetched past their end: wipe (the loader of the 8-row group does it, after its own data has landed)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int g = 2 * kt + hh;
-        if (wid == (g & 3)) {
-          const int i = 8 * hh + (lane >> 3), j0 = 2 * (lane & 7);
-          double *e = buf + (size_t)(16 * kt + i) * 16 + j0;
-          if (j0 > i) e[0] = 0.0;
-          if (j0 + 1 > i) e[1] = 0.0;
+        for (int hh = 0; hh < 2; ++hh) {
+          const int g = 2 * kt + hh;
+          if (lidx == g % nload) {
+            const int i = 8 * hh + (lane >> 3), j0 = 2 * (lane & 7);
+            double *e = buf + (size_t)(16 * kt + i) * 16 + j0;
+            if (j0 > i) e[0] = 0.0;
+            if (j0 + 1 > i) e[1] = 0.0;
+          }
         }
       }
+      STAMP(7);
       lds_barrier();
-      if (kt + 1 < NTL) issue2(kt + 1, lds + (size_t)(cur ^ 1) * B2);
+      STAMP(8);
+      if (kt + 1 < NTL && isload) issue2(kt + 1, lds + (size_t)(cur ^ 1) * B2);
+      STAMP(9);
       if (wact) {
         d4 t = (d4){0.0, 0.0, 0.0, 0.0};
         const double *bp = buf + l4 * 16 + l15;
+        // the B operands of row tile r + 1 are requested BEFORE the MFMAs of row tile r (two register sets, taken in turn; a
+        // scheduling barrier keeps the requests in front): every row tile is a basic block of its own (skipped for r < kt),
+        // and the compiler neither moves loads across those nor hoists them above MFMAs that still read the same registers
+        double b0[4], b1[4];
+        if (kt & 1) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { b1[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b0[q] = 0.0; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { b0[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b1[q] = 0.0; }
+        }
 #pragma unroll
         for (int r = 0; r < NTMAX; ++r) {
+          // (a computed entry -- switch (kt) with fall-through cases -- would save the compare + branch of every skipped tile,
+          // but the register allocator then needs > 512 VGPRs: measured, dropped)
           if (r >= kt && r < NTL) {   // workgroup-uniform
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this tile's operands (requested one tile ago) are here; said
+                                                  // explicitly (and visibly to the compiler), or it waits AFTER the new requests
+            if (r + 1 < NTMAX) {      // inside the buffer (B2 holds PMAX + 16 rows)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                if ((r & 1) == 0) b1[q] = bp[(16 * (r + 1) + 4 * q) * 16]; else b0[q] = bp[(16 * (r + 1) + 4 * q) * 16];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (4 * r + q < NKX) LCMFMA(kx[4 * r + q], bp[(16 * r + 4 * q) * 16], t);
+              if (4 * r + q < NKX) LCMFMA(kx[4 * r + q], (r & 1) == 0 ? b0[q] : b1[q], t);
           }
         }
         const int k = 16 * kt + l15;
@@ -248,6 +329,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
           }
         }
       }
+      STAMP(10);
       cur ^= 1;
     }
   }
@@ -277,4 +359,6 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
     A.loglik_c[b] = (double)m * HL2PI - 0.5 * wc;
     if (s_fail) atomicMin(A.errflag, B.level * 16 + 3);
   }
+  STAMP(11);
+  STAMP_FLUSH_LEVEL(B.level);
 }

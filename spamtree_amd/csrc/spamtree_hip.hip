@@ -3562,12 +3562,13 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     // k_factor_lchain: static + dynamic LDS must fit one CU's 160 KB, else the level stays on the older kernels
     hipFuncAttributes fa;
     size_t st96 = 16 * 1024, st136 = 16 * 1024;
-    if (hipFuncGetAttributes(&fa, (const void *)k_factor_lchain<96>) == hipSuccess) st96 = fa.sharedSizeBytes;
-    if (hipFuncGetAttributes(&fa, (const void *)k_factor_lchain<136>) == hipSuccess) st136 = fa.sharedSizeBytes;
+    bool ok96 = false, ok136 = false;   // a build whose unrolling failed keeps K in scratch memory (localSizeBytes > 0): never use that
+    if (hipFuncGetAttributes(&fa, (const void *)k_factor_lchain<96>) == hipSuccess) { st96 = fa.sharedSizeBytes; ok96 = fa.localSizeBytes == 0; }
+    if (hipFuncGetAttributes(&fa, (const void *)k_factor_lchain<136>) == hipSuccess) { st136 = fa.sharedSizeBytes; ok136 = fa.localSizeBytes == 0; }
     for (auto &L : h->levels) {
       if (!L.lchain) continue;
       const size_t need = lc_dyn_doubles(L.lchain) * 8 + (L.lchain == 96 ? st96 : st136);
-      if (need > 160 * 1024) L.lchain = 0;
+      if (need > 160 * 1024 || !(L.lchain == 96 ? ok96 : ok136)) L.lchain = 0;
     }
     (void)hipFuncSetAttribute((const void *)k_factor_lchain<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lc_dyn_doubles(96) * 8));
     (void)hipFuncSetAttribute((const void *)k_factor_lchain<136>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lc_dyn_doubles(136) * 8));
