@@ -388,7 +388,8 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
         }
         lds_barrier();
         if (sp == 1 && pf) issue(0, arena + (size_t)48 * ldS);
-        if (sr > 0) tile(buf, (sr + 3) >> 2, p_Kb, 0, sr);
+        // (row i of the sub-panel is chain row Pc + r0 + i of a LOWER-TRIANGULAR factor: nothing beyond column Pc + r0 + sr)
+        if (sr > 0) tile(buf, (sr + 3) >> 2, min(p_Kb, Pc + (sp == 0 ? 0 : p_sr0) + sr), 0, sr);
         lds_barrier();
       }
     }
@@ -424,7 +425,9 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       STAMP(3);
       if (i + 1 < nit) issue(i + 1, arena + (size_t)(cur ^ 1) * 32 * ldS);
       STAMP(6);
-      compute(buf, sr, Kb, RFL(s_rlen[c0 + min(sr, 16) - 1]));
+      // the chain's factor is lower triangular in chain order: a row's stored length runs to the end of its ancestor's block,
+      // but beyond the tile's last row index there are only (explicit) zeros -- 11 % of the V and 16 % of the T MFMAs at 25-row blocks
+      compute(buf, sr, min(Kb, c0 + 32), min(RFL(s_rlen[c0 + min(sr, 16) - 1]), c0 + 16));
       STAMP(4);
       cur ^= 1;
     }
