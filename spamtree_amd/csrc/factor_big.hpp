@@ -137,9 +137,12 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
           }
           __syncthreads();
           STAMP(2);
+          // the chain's factor is lower triangular in chain order: rows oa + r0 .. oa + r0 + sr - 1 hold nothing but (explicit)
+          // zeros beyond column oa + r0 + sr - 1, although their stored length runs to the end of the ancestor's block (Kb)
+          const int Kbe = min(Kb, oa + r0 + sr);
           if (pass == 0) {
-            // V_sub = Linv_sub[:, 0:Kb] K[0:Kb, :]: items (column tile jt, K slice ks), partial tiles summed through LDS
-            const int ns = (Kb + 3) >> 2;
+            // V_sub = Linv_sub[:, 0:Kbe] K[0:Kbe, :]: items (column tile jt, K slice ks), partial tiles summed through LDS
+            const int ns = (Kbe + 3) >> 2;
             const int per = (ns + BM_KS - 1) / BM_KS;   // K-steps per slice
             const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + l4;
             for (int it = wid; it < JT * BM_KS; it += BM_NT / 64) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
 #pragma unroll
             for (int c = 0; c < BM_KTW; ++c) {
               const int kt = kt0 + wid + (BM_NT / 64) * c;
-              if (wid + (BM_NT / 64) * c < BM_KTP && kt * 16 < Kb) {
+              if (wid + (BM_NT / 64) * c < BM_KTP && kt * 16 < Kbe) {
                 const double *b0 = stage + (size_t)l4 * ldS + kt * 16 + l15;
                 double bv[4];
 #pragma unroll
