@@ -4,7 +4,8 @@
 // Phase A of NON-REFERENCE blocks behind long ancestor chains (the leaves of the default multivariate tree, config #4:
 // 36-column blocks, chains of 525 rows; spamtree_model.cpp:923-963), third generation.  k_factor_bigmfma / k_factor_wide
 // keep K_{pa,u} and V in a global scratch slice and feed the matrix cores with 8-byte loads from L2 (56 % of the leaf level),
-// with three workgroup barriers per 16 chain rows.  Here a workgroup is ONE block and a wave owns 16 of its columns over the
+// with three workgroup barriers per 16 chain rows.  Here a workgroup is a slab of up to 64 columns of a sibling group (LcSlab)
+// and a wave owns 16 of its columns over the
 // WHOLE chain, as in k_factor_quad -- but a 525-row chain leaves no room for K AND the T = H_u accumulators in one wave's
 // registers, so the chain's inverse Cholesky factor (one lower-triangular P x P matrix kept as one row panel per ancestor)
 // is streamed through LDS TWICE and T is never held:
@@ -45,8 +46,43 @@ __device__ __forceinline__ double lc_cov(const double *tab, int q, double s2, do
   return a2 != 0.0 ? fma(a2, e2, r) : r;   // (a select, not a branch; r + a2 e2 rounds as the reference's sum does)
 }
 
+// A workgroup's columns: a SLAB of a sibling group -- up to 64 consecutive columns of the concatenated rows of consecutive
+// blocks with one parent (= one chain; device order keeps siblings, their rows and their panels contiguous).  Tiles of 16
+// columns may straddle blocks: four 36-column leaves are nine full tiles instead of twelve (16 + 16 + 4 each).
+struct LcSlab {
+  long long row0;   // first device row (column) of the slab
+  long long pan0;   // panel arena offset of that row's panel row (rows of the group follow each other with stride ld)
+  int blk0;         // a block of the group: chain, level
+  int ncol, ld, pad;
+};
+struct LcArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const LcSlab *slabs;
+  int nslab;
+  const double *cx, *cy;
+  const int *mv;
+  const double *w_in;
+  double *panels;
+  double *rowtmp;   // per device row: e_j^2 | log r_j (2 x n_rows), summed per block by k_lchain_scalars in row order
+  long long n_rows;
+  int *errflag;
+};
+
+// per-block scalars from the per-row values (fixed order: independent of the slabs' composition and of the launch geometry)
+__global__ void k_lchain_scalars(const Blk *blks, const int *list, int nlist, const double *rowtmp, long long n_rows, double *logdet_c, double *loglik_c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nlist) return;
+  const int b = list[i];
+  const Blk B = blks[b];
+  double wc = 0.0, ldt = 0.0;
+  for (int j = 0; j < B.m; ++j) { wc += rowtmp[B.row0 + j]; ldt += rowtmp[n_rows + B.row0 + j]; }
+  logdet_c[b] = ldt;
+  loglik_c[b] = (double)B.m * HL2PI - 0.5 * wc;
+}
+
 template <int NKX>
-__global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp) {
+__global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
   constexpr int PMAX = 4 * NKX, NTMAX = (PMAX + 15) / 16, ldS = lc_lds_stride(NKX);
   constexpr int B1 = 16 * ldS;             // doubles per phase-1 buffer (one 16-row tile, full length)
   constexpr int B2 = (PMAX + 16) * 16;     // doubles per phase-2 buffer (one 16-column block, row c at c * 16)
@@ -59,7 +95,6 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   __shared__ double s_wpa[PMAX];
   __shared__ long long s_rsrc[PMAX];   // chain row c: where it starts in the panel arena ...
   __shared__ int s_rlen[PMAX];         // ... and its length (entries up to the end of its own ancestor's rows)
-  __shared__ double s_e2[64], s_lg[64];
   __shared__ double s_cpt[3 * QMAX * QMAX + QMAX];   // rate, amp, amp2 per outcome pair, phi per outcome: the covariance pass reads
                                                      // them from LDS (as kernel arguments indexed per lane they are global loads,
                                                      // one dependent round trip per entry with a single wave per SIMD)
@@ -69,12 +104,12 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int li = blockIdx.x;
   {
-    const int per = A.nlist >> 3;   // one contiguous run of blocks per XCD (private L2): siblings share their chain's panels
+    const int per = A.nslab >> 3;   // one contiguous run of slabs per XCD (private L2): siblings share their chain's panels
     if (li < per * 8) li = (li & 7) * per + (li >> 3);
   }
-  const int b = A.list[li];
-  const Blk B = A.blks[b];
-  const int m = B.m, P = B.P, J = B.nanc;
+  const LcSlab S = A.slabs[li];
+  const Blk B = A.blks[S.blk0];
+  const int m = S.ncol, P = B.P, J = B.nanc;
   const int NTL = (P + 15) >> 4;
 
   for (int i = tid; i < (int)lc_dyn_doubles(NKX); i += LC_NT) lds[i] = 0.0;   // never NaN garbage under a zero multiplier
@@ -145,7 +180,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   const int jc = 16 * wid + l15;
   const bool cok = jc < m;
   const bool wact = 16 * wid < m;   // this wave owns at least one column
-  const long long jrow = B.row0 + min(jc, m - 1);
+  const long long jrow = S.row0 + min(jc, m - 1);
   const double mx = A.cx[jrow], my = A.cy[jrow], wj = A.w_in[jrow];
   const int mvj = A.mv[jrow];
   double kx[NKX];
@@ -259,8 +294,8 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
   };
   double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;   // hv = T w_pa for columns 4 q + l4, this lane's chain columns
   {
-    double *pu = A.panels + B.panel_off;
-    const int ld = B.ld;
+    double *pu = A.panels + S.pan0;
+    const int ld = S.ld;
     if (isload) issue2(0, lds);
     int cur = 0;
     for (int kt = 0; kt < NTL; ++kt) {
@@ -346,19 +381,13 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(FactorArgs A, CovPar cp
     const double hvc = (l15 >> 2) == 0 ? t0 : ((l15 >> 2) == 1 ? t1 : ((l15 >> 2) == 2 ? t2 : t3));
     if (cok && l4 == 0) {
       const double e = rj * (wj - hvc);
-      s_e2[jc] = e * e;
-      s_lg[jc] = log(rj);
-      A.panels[B.panel_off + (size_t)jc * B.ld + P] = rj;
+      A.rowtmp[jrow] = e * e;
+      A.rowtmp[A.n_rows + jrow] = log(rj);
+      A.panels[S.pan0 + (size_t)jc * S.ld + P] = rj;
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    double wc = 0.0, ldt = 0.0;
-    for (int j = 0; j < m; ++j) { wc += s_e2[j]; ldt += s_lg[j]; }
-    A.logdet_c[b] = ldt;
-    A.loglik_c[b] = (double)m * HL2PI - 0.5 * wc;
-    if (s_fail) atomicMin(A.errflag, B.level * 16 + 3);
-  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + 3);
   STAMP(11);
   STAMP_FLUSH_LEVEL(B.level);
 }

@@ -2625,6 +2625,7 @@ struct LevelInfo {
   int bm_ldS = 0;
   size_t lds_bigmfma = 0;
   int lchain = 0;                  // non-reference level on k_factor_lchain<lchain> (0: not used)
+  int lc_first = 0, lc_count = 0;  // its slabs (this rank's run) in d_lcslabs
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
   int own_lo = 0, own_n = 0, gown_lo = 0, gown_n = 0;   // this rank's run of the level's block list / group list
@@ -2652,6 +2653,9 @@ struct st_handle_s {
   std::vector<WideGrp> wgrps;                 // sibling groups of the wide levels (k_factor_wide)
   DevBuf<WideGrp> d_wgrps;
   int wide_on = 1;                            // SPAMTREE_WIDE=0: k_factor_bigmfma (one block per workgroup) instead
+  std::vector<LcSlab> lcslabs;                // k_factor_lchain: slabs of sibling groups
+  DevBuf<LcSlab> d_lcslabs;
+  DevBuf<double> d_lcrow;                     // per-row e^2 | log r of the lchain levels (2 n)
   int lchain_on = 1;                          // SPAMTREE_LCHAIN=0: non-reference long-chain levels stay on k_factor_wide / k_factor_bigmfma
   std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
   DevBuf<long long> d_gdesc;
@@ -2827,7 +2831,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_twin.free(); h->d_wgrps.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
+  h->d_twin.free(); h->d_wgrps.free(); h->d_lcslabs.free(); h->d_lcrow.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_err2.free(); h->d_toplist.free();
   if (h->ev_top) (void)hipEventDestroy(h->ev_top);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
@@ -3282,6 +3286,35 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       L.lds_wide = ((size_t)3 * (L.maxP + L.wide_maxN) + 2 * (size_t)L.wide_maxN + work) * 8 + (size_t)((L.maxP + L.wide_maxN + 1) & ~1) * 4 + 64;
       if (L.lds_wide > h->lds_limit) { h->wgrps.resize(L.wide_first); L.wide_count = 0; }
     }
+    // slabs for k_factor_lchain: sibling groups (consecutive blocks of this rank's run with the same last parent, contiguous
+    // rows AND panels, one row stride) cut into runs of <= 4 column tiles, as equal as possible (9 tiles -> 3 + 3 + 3)
+    L.lc_first = (int)h->lcslabs.size(); L.lc_count = 0;
+    if (L.lchain) {
+      int k = L.own_lo;
+      const int kend = L.own_lo + L.own_n;
+      while (k < kend) {
+        const int b0 = h->lvl_list[L.first + k];
+        const Blk &B0 = h->blks[b0];
+        const int lastp = h->anc_idx[B0.anc_ptr + B0.nanc - 1];
+        int cnt = 1, Ncols = B0.m;
+        while (k + cnt < kend && cnt < 16) {
+          const int b1 = h->lvl_list[L.first + k + cnt];
+          const Blk &B1 = h->blks[b1];
+          if (b1 != b0 + cnt || B1.nanc != B0.nanc || h->anc_idx[B1.anc_ptr + B1.nanc - 1] != lastp || B1.P != B0.P || B1.ld != B0.ld ||
+              B1.row0 != B0.row0 + Ncols || B1.panel_off != B0.panel_off + (long long)Ncols * B0.ld) break;
+          Ncols += B1.m; ++cnt;
+        }
+        const int JT = (Ncols + 15) / 16, nsl = (JT + 3) / 4, tps = (JT + nsl - 1) / nsl;
+        for (int s0 = 0; s0 < Ncols; s0 += 16 * tps) {
+          LcSlab S;
+          S.row0 = B0.row0 + s0; S.pan0 = B0.panel_off + (long long)s0 * B0.ld; S.blk0 = b0;
+          S.ncol = std::min(16 * tps, Ncols - s0); S.ld = B0.ld; S.pad = 0;
+          h->lcslabs.push_back(S);
+          ++L.lc_count;
+        }
+        k += cnt;
+      }
+    }
     // quads for k_factor_quad: runs of up to quad_nu column groups of one rank that share their ancestor chain
     // (reference levels) or the chain without its last ancestor (leaf levels: cousins)
     L.quad_first = (int)h->quads.size(); L.quad_count = 0; L.q_nkx = 0; L.qown_lo = 0; L.qown_n = 0;
@@ -3480,6 +3513,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   }
   { std::vector<Quad> g = h->quads; if (g.empty()) g.push_back(Quad{0, 0, 0, 0}); CCHK(h->d_quads.upload(g)); }
   { std::vector<WideGrp> g = h->wgrps; if (g.empty()) g.push_back(WideGrp{0, 0}); CCHK(h->d_wgrps.upload(g)); }
+  if (!h->lcslabs.empty()) { CCHK(h->d_lcslabs.upload(h->lcslabs)); CCHK(h->d_lcrow.alloc((size_t)2 * h->n_all)); }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
   { std::vector<int> a = h->own_obs_list; if (a.empty()) a.push_back(0); CCHK(h->d_ownobs.upload(a)); }
@@ -3883,8 +3917,15 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         hipLaunchKernelGGL(k_factor_mfma, dim3(L.gown_n), dim3(NT), L.lds_fast, st, F, cp);
       } else if (L.bigmfma && h->factor_gen == 3 && L.lchain) {
-        if (L.lchain == 96) hipLaunchKernelGGL((k_factor_lchain<96>), dim3(A.nlist), dim3(LC_NT), lc_dyn_doubles(96) * 8, st, A, cp);
-        else hipLaunchKernelGGL((k_factor_lchain<136>), dim3(A.nlist), dim3(LC_NT), lc_dyn_doubles(136) * 8, st, A, cp);
+        LcArgs C;
+        std::memset(&C, 0, sizeof(C));
+        C.blks = h->d_blks.p; C.anc_idx = h->d_anc.p; C.slabs = h->d_lcslabs.p + L.lc_first; C.nslab = L.lc_count;
+        C.cx = h->d_cx.p; C.cy = h->d_cy.p; C.mv = h->d_mv.p; C.w_in = h->d_w.p; C.panels = h->d_panels[phys].p;
+        C.rowtmp = h->d_lcrow.p; C.n_rows = h->n_all; C.errflag = errflag;
+        if (L.lchain == 96) hipLaunchKernelGGL((k_factor_lchain<96>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(96) * 8, st, C, cp);
+        else hipLaunchKernelGGL((k_factor_lchain<136>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(136) * 8, st, C, cp);
+        hipLaunchKernelGGL(k_lchain_scalars, dim3((A.nlist + 255) / 256), dim3(256), 0, st, h->d_blks.p, A.list, A.nlist, h->d_lcrow.p, h->n_all,
+                           h->d_logdet[phys].p, h->d_loglik[phys].p);
       } else if (L.bigmfma && h->factor_gen == 3 && L.wide_count > 0) {
         WideArgs W;
         std::memset(&W, 0, sizeof(W));
