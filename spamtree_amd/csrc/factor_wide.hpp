@@ -18,7 +18,7 @@
 #define WG_JT 10
 #define WG_NT 512
 // lower-triangular trimming (as in k_factor_quad / k_factor_bigmfma): bit 0 = the V phase's K-steps, bit 1 = the T phase's chain tiles.
-// Each alone reproduces the oracle; BOTH together fail tests/test_gpu_deep.py on this kernel (deterministically; not understood --
+// Each alone passes the parity tests; BOTH together fail tests/test_gpu_deep.py on this kernel (deterministically; not understood --
 // the same pair is fine in k_factor_bigmfma), so only the V phase is trimmed here.  The kernel is a fallback now (non-reference
 // levels wider than 64 columns, or SPAMTREE_LCHAIN=0).
 #ifndef WIDE_TRIM

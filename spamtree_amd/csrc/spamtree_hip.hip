@@ -1139,6 +1139,89 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 #include "factor_wide.hpp"
 #include "factor_lchain.hpp"
 
+// w = L^{-T} (L^{-1} b + z), S = L L' (spamtree_model.cpp:1054, 1086), for blocks too wide for one wave's registers (75-row
+// blocks of the default multivariate tree), by ONE wave with S in LDS and NO workgroup barrier: the scratch-arena path pays
+// three __syncthreads() per pivot for the factorisation and four per row for the two substitutions (about a millisecond per
+// 75-row block, most of phase B at config #4).  Lane i owns rows i and i + 64 (m <= 128); right-looking elimination, the
+// scaled pivot column goes through `lcol` (m doubles of LDS) so that a batch of eight trailing columns costs four wide
+// uniform reads; the right-hand side rides along (forward substitution for free); the backward substitution walks L by rows.
+//   S: m x m (m <= 80), row stride ms (odd: conflict-free column walks; >= m + 7), lower triangle valid, destroyed.
+//   lcol: m + 8 doubles.  bv (LDS): in b, out w.
+//   zg: the block's normals (global).  All 64 lanes of the wave must call; nobody else may touch S, lcol, bv meanwhile.
+__device__ __forceinline__ void wave_chol_solve_lds(double *S, int ms, double *lcol, double *bv, const double *zg, int m, int *fail, int lane) {
+  // rows 0 .. 63: lane i owns row i.  Rows 64 .. m - 1 (at most 16: m <= 80): lane (g, r) = (lane >> 4, lane & 15) works on
+  // row 64 + r, and the four lane groups take DIFFERENT column batches of one trip (eleven rows on a row-per-lane mapping
+  // would pay a whole wave-instruction stream for 17 % of its lanes)
+  const int i0 = lane, i1 = 64 + (lane & 15), g1 = lane >> 4;
+  const bool r0 = i0 < m, r1 = i1 < m;
+  const bool two = m > 64;   // wave-uniform
+  double c0 = r0 ? bv[i0] : 0.0, c1 = r1 ? bv[i1] : 0.0;   // c1, dr1, t1: replicated in the four lanes of a row
+  double dr0 = 1.0, dr1 = 1.0;   // 1 / L_kk of this lane's rows
+  bool bad = false;
+  for (int j = lane; j < m + 8; j += 64) lcol[j] = 0.0;
+  for (int k = 0; k < m; ++k) {
+    const double d = S[(size_t)k * ms + k];
+    bad = bad || !(d > 0.0);
+    double rp = __builtin_amdgcn_rsq(d);            // 1 / sqrt(d): hardware seed + two Newton steps (relative error < 1e-16)
+    rp = rp * fma(-0.5 * d * rp, rp, 1.5);
+    rp = rp * fma(-0.5 * d * rp, rp, 1.5);
+    const bool u0 = r0 && i0 > k, u1 = r1 && i1 > k;
+    const double l0 = u0 ? S[(size_t)i0 * ms + k] * rp : 0.0;
+    const double l1 = u1 ? S[(size_t)i1 * ms + k] * rp : 0.0;
+    const double ck = readlane_f64(k < 64 ? c0 : c1, k & 63);   // (row 64 + r: lane r of group 0)
+    const double yk = ck * rp;
+    c0 = (i0 == k) ? yk : fma(-l0, yk, c0);
+    c1 = (i1 == k) ? yk : fma(-l1, yk, c1);
+    dr0 = (i0 == k) ? rp : dr0;
+    dr1 = (i1 == k) ? rp : dr1;
+    if (u0) { S[(size_t)i0 * ms + k] = l0; lcol[i0] = l0; }
+    if (u1 && g1 == 0) { S[(size_t)i1 * ms + k] = l1; lcol[i1] = l1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: its LDS operations complete in order
+    // trailing columns in batches of eight, WITHOUT per-element predicates: rows at or above the pivot carry l = 0 (no-ops),
+    // entries above the diagonal and the columns past m - 1 that a batch reaches (row stride ms >= m + 7, lcol: m + 8) are
+    // scribbled on and never read
+    if (r0) {
+      double *row = S + (size_t)i0 * ms;
+      for (int j0 = k + 1; j0 < m; j0 += 8) {
+        // (requesting the next batch before this one's stores would save about a tenth of the solve, but its 16 extra VGPRs
+        // take the kernel past 128 and the leaf levels, which share it, from four waves per SIMD to three: measured, dropped)
+        double lj[8], a0[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lj[q] = lcol[j0 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a0[q] = row[j0 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) row[j0 + q] = fma(-l0, lj[q], a0[q]);
+      }
+    }
+    if (two) {   // wave-uniform
+      if (r1) {
+        double *row = S + (size_t)i1 * ms;
+        for (int j0 = k + 1 + 8 * g1; j0 < m; j0 += 32) {
+          double lj[8], a1[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) lj[q] = lcol[j0 + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a1[q] = row[j0 + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) row[j0 + q] = fma(-l1, lj[q], a1[q]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (bad && lane == 0) *fail = 1;
+  // S now holds L below the diagonal (column k scaled by 1 / L_kk); c = L^{-1} b.  Backward: w_k = t_k / L_kk, t_j -= L_kj w_k
+  double t0 = r0 ? c0 + zg[i0] : 0.0, t1 = r1 ? c1 + zg[i1] : 0.0;
+  for (int k = m - 1; k >= 0; --k) {
+    const double wk = readlane_f64(k < 64 ? t0 : t1, k & 63) * readlane_f64(k < 64 ? dr0 : dr1, k & 63);
+    t0 = (i0 == k) ? wk : ((r0 && i0 < k) ? fma(-S[(size_t)k * ms + i0], wk, t0) : t0);
+    if (two) t1 = (i1 == k) ? wk : ((r1 && i1 < k) ? fma(-S[(size_t)k * ms + i1], wk, t1) : t1);
+  }
+  if (r0) bv[i0] = t0;
+  if (r1 && g1 == 0) bv[i1] = t1;
+}
+
 struct SampleArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -1157,7 +1240,10 @@ struct SampleArgs {
   int maxP, maxM, maxLd;
   int do_gram;
   int no_fwd;   // limited_tree: a block's record goes to its single parent only, nothing is forwarded from its children
-  int lds_sq;   // BIG: the posterior precision and its inverse Cholesky factor (2 maxM^2 doubles) live in LDS, after the vectors
+  int lds_sq;   // BIG: 2 = the posterior precision lives in LDS after the vectors (maxM x (maxM | 1) + maxM doubles) and ONE wave
+                // factorises and solves there (wave_chol_solve_lds); 0 = scratch arena + workgroup-wide loops
+  double *s0;              // theta-only part Ri' Ri of every reference block's posterior precision, cached like the records'
+  const long long *s0off;  // Gram parts: per block, offset into s0 (row stride m) or -1
   double tausq_inv[QMAX];
 };
 
@@ -1167,6 +1253,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
   __shared__ int s_fail;
+  __shared__ long long s_choff[16];    // record offsets of the first direct children (one read per block instead of one per entry)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int maxP = A.maxP, maxM = A.maxM;
@@ -1178,19 +1265,23 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   double *seg = av + maxM;             // MAXJ * maxM: seg[t][r] = sum_j N[r][oa_t + j] w_a[j], later ev[r] - seg[t][r]
   double *Np = seg + (size_t)MAXJ * maxM;   // !BIG: maxM * maxLd panel copy
   double *S = BIG ? (A.lds_sq ? Np : A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
-  double *Li = S + (size_t)maxM * maxM;   // BIG with lds_sq only
 
+  STAMP_DECL
+  int st_lev = 0;
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
     const int b = A.list[li];
     const Blk B = A.blks[b];
     const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+    st_lev = B.level;
     __syncthreads();
+    STAMP(7);
     if (tid < J) {
       const int a = A.anc_idx[B.anc_ptr + tid];
       s_am[tid] = A.blks[a].m;
       s_arow[tid] = A.blks[a].row0;
     }
     if (tid == 0) s_fail = 0;
+    if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
     __syncthreads();
     if (tid == 0) {
       int o = 0;
@@ -1212,60 +1303,75 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       N = Np;
     }
     __syncthreads();
-    for (int i = wid; i < m; i += NT / 64) {
-      double acc = 0.0;
-      for (int k = lane; k < P; k += 64) acc += N[(size_t)i * ld + k] * wv[k];
-      acc = wave_sum(acc);
-      if (lane == 0) tv[i] = acc;
+    for (int i0 = 4 * wid; i0 < m; i0 += 4 * (NT / 64)) {   // four rows per trip: their loads travel together
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < P; k += 64) {
+        const double wk = wv[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (i0 + q < m) a4[q] += N[(size_t)(i0 + q) * ld + k] * wk;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double r = wave_sum(a4[q]);
+        if (lane == 0 && i0 + q < m) tv[i0 + q] = r;
+      }
     }
     __syncthreads();
 
+    STAMP(0);
     if (B.isref) {
       const double *Ri = N + P;  // Ri[i][j] = N[i*ld + P + j]
       // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
+      const int ms = (BIG && A.lds_sq) ? ((m + 7) | 1) : m;   // row stride of S
+      const long long so = (BIG && A.s0off) ? A.s0off[b] : -1;
+#pragma unroll 4
       for (int idx = tid; idx < m * m; idx += NT) {
         const int i = idx / m, j = idx - i * m;
         if (j <= i) {
           double acc = 0.0;
-          for (int k = i; k < m; ++k) acc += Ri[(size_t)k * ld + i] * Ri[(size_t)k * ld + j];
+          if (so >= 0 && !A.do_gram) acc = A.s0[so + idx];   // Ri' Ri is a function of theta only
+          else {
+            for (int k = i; k < m; ++k) acc += Ri[(size_t)k * ld + i] * Ri[(size_t)k * ld + j];
+            if (so >= 0) A.s0[so + idx] = acc;
+          }
           for (int c = 0; c < B.ndch; ++c) {
-            const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
-            acc += A.acc[C.acc_off + B.acc_len + idx];
+            const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
+            acc += A.acc[co + B.acc_len + idx];
           }
           if (i == j) acc += A.tausq_inv[A.mv[B.row0 + i]];
-          S[idx] = acc;
+          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = acc; else S[(size_t)i * ms + j] = acc;
         } else {
-          S[idx] = 0.0;
+          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = 0.0; else S[(size_t)i * ms + j] = 0.0;
         }
       }
       // Smu_tot = A_u' w_pa + sum_children Smu_children + tausq_inv*(y - XB)   (:1062-1077)
       for (int i = tid; i < m; i += NT) {
         double acc = 0.0;
-        for (int k = i; k < m; ++k) acc -= Ri[(size_t)k * ld + i] * tv[k];
+        // - Ri' (N w_pa), walking Ri by ROWS (thread i reads entry i of row k: coalesced; same summation order as the column walk)
+        for (int k0 = 0; k0 < m; k0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) x[q] = (k0 + q < m && k0 + q >= i) ? Ri[(size_t)(k0 + q) * ld + i] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (k0 + q < m && k0 + q >= i) acc -= x[q] * tv[k0 + q];
+        }
         for (int c = 0; c < B.ndch; ++c) {
-          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
-          acc += A.acc[C.acc_off + B.acc_len + m * m + i];
+          const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
+          acc += A.acc[co + B.acc_len + m * m + i];
         }
         const long long r = B.row0 + i;
         acc += A.tausq_inv[A.mv[r]] * (A.y[r] - A.xb[r]);
         bv[i] = acc;
       }
       if (BIG && A.lds_sq) {
-        // w_u = Li' (Li Smu + z) with Li = chol(S)^{-1} from the one-barrier-per-pivot elimination: two matrix-vector
-        // products instead of a forward and a backward substitution of m barrier pairs each (wide blocks: m up to 80)
+        // w_u = L^{-T} (L^{-1} Smu + z) by wave 0 alone, S in LDS (no workgroup barrier inside)
         __syncthreads();
-        block_chol_invert(S, Li, m, &s_fail);
-        for (int i = tid; i < m; i += NT) {
-          double acc = A.z[B.row0 + i];
-          for (int j = 0; j <= i; ++j) acc += Li[i * m + j] * bv[j];
-          av[i] = acc;
-        }
-        __syncthreads();
-        for (int j = tid; j < m; j += NT) {
-          double acc = 0.0;
-          for (int i = j; i < m; ++i) acc += Li[i * m + j] * av[i];
-          bv[j] = acc;
-        }
+        STAMP(1);
+        // (Np, not S: S is `lds_sq ? LDS : scratch arena`, a generic pointer -- the compiler would emit FLAT loads and stores,
+        // six times slower than ds_read / ds_write here)
+        if (wid == 0) wave_chol_solve_lds(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail, lane);
       } else {
       chol_lower_inplace(S, m, &s_fail);
       // w_u = L^{-T} (L^{-1} Smu + z)   (= Sigi_chol' (Sigi_chol Smu + z), :1086)
@@ -1287,6 +1393,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       }
       }
       __syncthreads();
+      STAMP(2);
       for (int i = tid; i < m; i += NT) {
         wv[P + i] = bv[i];
         A.w[B.row0 + i] = bv[i];
@@ -1314,6 +1421,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       }
     }
     __syncthreads();
+    STAMP(3);
     // messages to every ancestor (:1158-1207), summed with the direct children's accumulated messages
     if (!A.do_gram) {
       // Gram parts cached (Q4): only the vectors.  All ancestors at once, as in k_sample_lean: thread (row r, ancestor t)
@@ -1334,6 +1442,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         seg[t * maxM + r] = ev[r] - a;
       }
       __syncthreads();
+      STAMP(4);
       double *rec = A.acc + B.acc_off;
       for (int k = tid; k < P; k += NT) {
         int t = 0;
@@ -1354,6 +1463,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         }
         rec[s_aoff[t] + ma * ma + i] = a;
       }
+      STAMP(5);
       if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
       continue;
     }
@@ -1387,6 +1497,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     }
     if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
   }
+  STAMP_FLUSH_LEVEL(st_lev);
 }
 
 
@@ -2656,6 +2767,8 @@ struct st_handle_s {
   std::vector<LcSlab> lcslabs;                // k_factor_lchain: slabs of sibling groups
   DevBuf<LcSlab> d_lcslabs;
   DevBuf<double> d_lcrow;                     // per-row e^2 | log r of the lchain levels (2 n)
+  DevBuf<double> d_s0;                        // Ri' Ri of the reference blocks on the generic phase-B path (theta-only, cached with the Gram parts)
+  DevBuf<long long> d_s0off;                  // per block: offset into d_s0, -1 = none
   int lchain_on = 1;                          // SPAMTREE_LCHAIN=0: non-reference long-chain levels stay on k_factor_wide / k_factor_bigmfma
   std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
   DevBuf<long long> d_gdesc;
@@ -2812,7 +2925,7 @@ static size_t lds_factor_bytes(int maxP, int maxM, int maxMa, int SR, bool big) 
 static size_t scratch_factor_doubles(int maxP, int maxM, int maxMa) {
   return (size_t)2 * maxP * maxM + (size_t)maxMa * maxM + (size_t)2 * maxM * maxM;
 }
-static size_t lds_sample_sq_bytes(int maxM) { return (size_t)2 * maxM * maxM * 8; }
+static size_t lds_sample_sq_bytes(int maxM) { return ((size_t)maxM * ((maxM + 7) | 1) + maxM + 16) * 8; }   // S (odd row stride) + the pivot column
 static size_t lds_sample_bytes(int maxP, int maxM, int maxLd, bool big) {
   size_t dbl = (size_t)(maxP + maxM) + 4 * (size_t)maxM + (size_t)MAXJ * maxM;   // ... + segment sums seg[t][r]
   if (!big) dbl += (size_t)maxM * maxLd + (size_t)maxM * maxM;
@@ -2831,7 +2944,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_twin.free(); h->d_wgrps.free(); h->d_lcslabs.free(); h->d_lcrow.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
+  h->d_twin.free(); h->d_wgrps.free(); h->d_lcslabs.free(); h->d_lcrow.free(); h->d_s0.free(); h->d_s0off.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_err2.free(); h->d_toplist.free();
   if (h->ev_top) (void)hipEventDestroy(h->ev_top);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
@@ -3105,10 +3218,10 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     L.big_sample = h->force_generic || L.lds_sample > h->lds_limit;
     if (L.big_sample) {
       L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, true);
-      // measured at config #4: with 100 KB of LDS only one workgroup fits a CU, and on levels with more blocks than 2 x CUs the
-      // four co-resident workgroups of the scratch-arena path hide more latency (4.7 ms) than the fewer barriers save (7.8 ms);
-      // levels of at most 2 x CUs blocks are latency chains of single workgroups: 0.52 -> 0.41 ms
-      if (L.isref && L.count <= 2 * h->sm_count && L.lds_sample + lds_sample_sq_bytes(L.maxM) <= h->lds_limit) {
+      // the posterior precision in LDS, factorised and solved by ONE wave without workgroup barriers (wave_chol_solve_lds):
+      // every reference level where it fits (config #4: 74 KB, two workgroups per CU).  [The earlier LDS variant -- S and
+      // chol(S)^-1, 100 KB, one barrier per pivot -- only paid on levels of at most 2 x CUs blocks.]
+      if (L.isref && L.maxM <= 80 && L.lds_sample + lds_sample_sq_bytes(L.maxM) <= h->lds_limit) {
         L.lds_sample += lds_sample_sq_bytes(L.maxM); L.sample_sq = true;
       }
     }
@@ -3514,6 +3627,21 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   { std::vector<Quad> g = h->quads; if (g.empty()) g.push_back(Quad{0, 0, 0, 0}); CCHK(h->d_quads.upload(g)); }
   { std::vector<WideGrp> g = h->wgrps; if (g.empty()) g.push_back(WideGrp{0, 0}); CCHK(h->d_wgrps.upload(g)); }
   if (!h->lcslabs.empty()) { CCHK(h->d_lcslabs.upload(h->lcslabs)); CCHK(h->d_lcrow.alloc((size_t)2 * h->n_all)); }
+  {
+    std::vector<long long> s0off((size_t)(nb > 0 ? nb : 1), -1);
+    size_t tot = 0;
+    for (int g = 0; g < n_actual; ++g) {
+      const LevelInfo &L = h->levels[g];
+      if (!L.big_sample || !L.isref) continue;
+      for (int k = 0; k < L.count; ++k) {
+        const int b = h->lvl_list[L.first + k];
+        s0off[b] = (long long)tot;
+        tot += (size_t)h->blks[b].m * h->blks[b].m;
+      }
+    }
+    CCHK(h->d_s0off.upload(s0off));
+    CCHK(h->d_s0.alloc(std::max(tot, (size_t)1)));
+  }
   { std::vector<int> a = h->pred_list; if (a.empty()) a.push_back(0); CCHK(h->d_pred.upload(a)); }
   CCHK(h->d_allobs.upload(h->all_obs_list));
   { std::vector<int> a = h->own_obs_list; if (a.empty()) a.push_back(0); CCHK(h->d_ownobs.upload(a)); }
@@ -4211,7 +4339,8 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
     for (int j = 0; j < QMAX; ++j) A.tausq_inv[j] = h->tausq_inv[j];
     A.do_gram = (h->gram_valid && h->cache_gram) ? 0 : 1;
     A.no_fwd = h->limited ? 1 : 0;
-    A.lds_sq = (L.big_sample && L.sample_sq) ? 1 : 0;
+    A.lds_sq = (L.big_sample && L.sample_sq) ? 2 : 0;
+    A.s0 = h->d_s0.p; A.s0off = h->d_s0off.p;
     {
       ProfScope ps(h, 1, h->n_actual_groups + g);   // per-level slots of phase B follow those of phase A
       if (L.fast) {
