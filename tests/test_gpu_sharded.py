@@ -18,6 +18,8 @@ def free_port():
 
 @pytest.mark.parametrize("side,q,quad_min,env", [(120, 1, None, {}), (48, 3, None, {}), (120, 1, "1", {}),
                                                  (48, 3, None, {"SPAMTREE_WIDE": "2"}),          # sibling-group kernel on every wide level
+                                                 (40, 3, None, {"LCHAIN": "expected"}),           # 50-row leaves behind 225-row chains: k_factor_lchain
+                                                                                                 # (slabs cut inside a rank's run) + the one-wave LDS solve
                                                  (120, 1, "1", {"SPAMTREE_SAMPLE_WAVE": "2"})])  # one block per wave in the sweep
 def test_sharded_equals_single_process_bitwise(side, q, quad_min, env, tmp_path, monkeypatch):
     """quad_min = "1": even these small levels take k_factor_quad (SPAMTREE_QUAD_MIN, inherited by the spawned ranks),
@@ -25,6 +27,8 @@ def test_sharded_equals_single_process_bitwise(side, q, quad_min, env, tmp_path,
     workgroup in the single process, 2 with two ranks, 1 with three) -- the results must not depend on how they are cut."""
     if quad_min:
         monkeypatch.setenv("SPAMTREE_QUAD_MIN", quad_min)
+    env = dict(env)
+    expect_lchain = env.pop("LCHAIN", None) is not None
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     units = {1: "4", 2: "2", 3: "1", 4: None}     # None: the library's own choice for the rank's share of a level
@@ -38,6 +42,8 @@ def test_sharded_equals_single_process_bitwise(side, q, quad_min, env, tmp_path,
             monkeypatch.setenv("SPAMTREE_QUAD_UNITS", units[world])
         mp.spawn(gpu_worker, args=(world, free_port(), side, q, str(tmp_path), steps), nprocs=world, join=True)
     ref = np.load(tmp_path / "res_1_0.npz")
+    if expect_lchain:
+        assert 6 in ref["kernels"].tolist(), ref["kernels"]      # ST_KERNEL_LCHAIN: the case reaches the kernel it is meant to cover
     for world in (2, 3, 4):
         rows = 0
         for rank in range(world):
