@@ -1501,6 +1501,103 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
 }
 
 
+// The theta-only parts of the generic path's message records -- Sigma_a = N_a' N_a per ancestor a, plus the direct children's
+// (spamtree_model.cpp:1162, 1190-1192) -- and of the posterior precision (Ri' Ri) on the FP64 matrix cores,
+// ahead of a sweep that then takes k_sample's cached branch.  k_sample's own do_gram branch builds them with one thread per
+// entry and a strided global walk per product: 35 ms for the leaf level of config #4 (16 384 blocks x 7 ancestors x 75 x 75
+// entries x 36 rows) against 2.2 ms for the sweep itself.  One workgroup per block; a task = one 16 x 16 tile (it >= jt) of
+// one ancestor's Gram matrix, tasks dealt over the four waves; both MFMA operands are rows of the block's panel, straight
+// from global memory / L2 (16 consecutive doubles per row: whole 128-byte segments).  Fixed summation order.
+struct GramBigArgs {
+  const Blk *blks;
+  const int *anc_idx, *dch_idx;
+  const int *list;
+  int nlist;
+  const double *panels;
+  double *acc;
+  double *s0;
+  const long long *s0off;
+  int no_fwd;
+};
+
+__global__ __launch_bounds__(NT) void k_gram_big(GramBigArgs A) {
+  __shared__ int s_am[MAXJ + 1], s_ao[MAXJ + 1], s_t0[MAXJ + 2];
+  __shared__ long long s_aoff[MAXJ + 1];
+  __shared__ long long s_choff[16];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = A.list[blockIdx.x];
+  const Blk B = A.blks[b];
+  const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+  const long long so = (B.isref && A.s0off) ? A.s0off[b] : -1;
+  if (tid < J) s_am[tid] = A.blks[A.anc_idx[B.anc_ptr + tid]].m;
+  if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0, tasks = 0;
+    long long ao = 0;
+    for (int t = 0; t < J; ++t) {
+      const int nt = (s_am[t] + 15) >> 4;
+      s_ao[t] = o; s_aoff[t] = ao; s_t0[t] = tasks;
+      o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; tasks += nt * (nt + 1) / 2;
+    }
+    s_t0[J] = tasks;
+    if (so >= 0) { s_am[J] = m; s_ao[J] = P; s_aoff[J] = 0; const int nt = (m + 15) >> 4; tasks += nt * (nt + 1) / 2; }
+    s_t0[J + 1] = tasks;
+  }
+  __syncthreads();
+  const double *N = A.panels + B.panel_off;
+  double *rec = A.acc + B.acc_off;
+  const int ntask = s_t0[J + 1], ns = (m + 3) >> 2;
+  const int nch = A.no_fwd ? 0 : B.ndch;
+  for (int e = wid; e < ntask; e += NT / 64) {
+    int t = 0;
+    while (e >= s_t0[t + 1]) ++t;
+    int it = 0, pe = e - s_t0[t];
+    while ((it + 1) * (it + 2) / 2 <= pe) ++it;
+    const int jt = pe - it * (it + 1) / 2;
+    const int ma = s_am[t], oa = s_ao[t];
+    const int ci = 16 * it + l15, cj = 16 * jt + l15;
+    const double *ap = N + (size_t)l4 * ld + oa + min(ci, ma - 1), *bp = N + (size_t)l4 * ld + oa + min(cj, ma - 1);
+    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+    int st = 0;
+    for (; st + 4 <= ns; st += 4) {   // eight operand loads in flight per lane
+      double a4[4], b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool rok = 4 * (st + q) + l4 < m;
+        a4[q] = (rok && ci < ma) ? ap[(size_t)4 * (st + q) * ld] : 0.0;
+        b4[q] = (rok && cj < ma) ? bp[(size_t)4 * (st + q) * ld] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
+    }
+    for (; st < ns; ++st) {
+      const bool rok = 4 * st + l4 < m;
+      const double a1 = (rok && ci < ma) ? ap[(size_t)4 * st * ld] : 0.0, b1 = (rok && cj < ma) ? bp[(size_t)4 * st * ld] : 0.0;
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+    }
+    // C layout: entry (i = 16 it + 4 q + l4, j = 16 jt + l15); the mirrored entry of an off-diagonal tile gets the same value
+    const bool isS0 = t == J;
+    double *out = isS0 ? A.s0 + so : rec + s_aoff[t];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 16 * it + 4 * q + l4, j = cj;
+      if (i < ma && j < ma) {
+        double v = c[q];
+        if (!isS0) {
+          for (int ch = 0; ch < nch; ++ch) {
+            const long long co = ch < 16 ? s_choff[ch] : A.blks[A.dch_idx[B.dch_ptr + ch]].acc_off;
+            v += A.acc[co + s_aoff[t] + (size_t)i * ma + j];
+          }
+        }
+        out[(size_t)i * ma + j] = v;
+        if (it != jt) out[(size_t)j * ma + i] = v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Phase B, fast path: one workgroup per column group (same groups as k_factor_mfma).  A sibling group of
 // non-reference blocks is treated as ONE block with a diagonal Ri: the Gram of the stacked panel rows is the sum
@@ -2769,6 +2866,7 @@ struct st_handle_s {
   DevBuf<double> d_lcrow;                     // per-row e^2 | log r of the lchain levels (2 n)
   DevBuf<double> d_s0;                        // Ri' Ri of the reference blocks on the generic phase-B path (theta-only, cached with the Gram parts)
   DevBuf<long long> d_s0off;                  // per block: offset into d_s0, -1 = none
+  int gram_big = 1;                           // SPAMTREE_GRAM_BIG=0: the generic sweep kernel rebuilds the records' Gram parts itself (one thread per entry)
   int lchain_on = 1;                          // SPAMTREE_LCHAIN=0: non-reference long-chain levels stay on k_factor_wide / k_factor_bigmfma
   std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
   DevBuf<long long> d_gdesc;
@@ -3187,6 +3285,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     h->quad_nu = 4;   // units per workgroup of k_factor_quad (2 per workgroup with two workgroups per CU measured slower)
     { const char *e = getenv("SPAMTREE_WIDE"); h->wide_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
     { const char *e = getenv("SPAMTREE_LCHAIN"); h->lchain_on = (e && e[0] == '0') ? 0 : 1; }
+    { const char *e = getenv("SPAMTREE_GRAM_BIG"); h->gram_big = (e && e[0] == '0') ? 0 : 1; }
   }
   h->levels.resize(n_actual);
   auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
@@ -4368,11 +4467,22 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
           F.ldN = (int)per; F.Mrows = L.maxM;
           hipLaunchKernelGGL(k_sample_wave, dim3((L.gown_n + NT / 64 - 1) / (NT / 64)), dim3(NT), per * 8 * (NT / 64), h->stream, F);
         } else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
-      } else if (L.big_sample) {
-        A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
-        hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
       } else {
-        hipLaunchKernelGGL((k_sample<false>), dim3(L.own_n), dim3(NT), L.lds_sample, h->stream, A);
+        if (A.do_gram && L.big_sample && h->gram_big) {
+          // the theta-only parts first, on the matrix cores (k_gram_big); the sweep kernel then takes its cached branch
+          GramBigArgs Gb;
+          std::memset(&Gb, 0, sizeof(Gb));
+          Gb.blks = h->d_blks.p; Gb.anc_idx = h->d_anc.p; Gb.dch_idx = h->d_dch.p; Gb.list = A.list; Gb.nlist = A.nlist;
+          Gb.panels = A.panels; Gb.acc = A.acc; Gb.s0 = A.s0; Gb.s0off = A.s0off; Gb.no_fwd = A.no_fwd;
+          hipLaunchKernelGGL(k_gram_big, dim3(A.nlist), dim3(NT), 0, h->stream, Gb);
+          A.do_gram = 0;
+        }
+        if (L.big_sample) {
+          A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
+          hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
+        } else {
+          hipLaunchKernelGGL((k_sample<false>), dim3(L.own_n), dim3(NT), L.lds_sample, h->stream, A);
+        }
       }
     }
     HCHK(h, hipGetLastError());
