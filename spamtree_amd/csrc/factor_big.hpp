@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
       }
       __syncthreads();
       STAMP(7);
-      block_chol_invert(Rl, Ril, m, &s_fail);
+      block_chol_invert_mfma(Rl, Ril, m, &s_fail);
       STAMP(8);
       // panel_u = [ -Ri*T | Ri ]: tiles (row tile it, chain tile kt), A = -Ri from LDS, B = T from the scratch slice
       {

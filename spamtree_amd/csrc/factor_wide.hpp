@@ -284,7 +284,7 @@ __global__ __launch_bounds__(WG_NT, 2) void k_factor_wide(WideArgs A, CovPar cp)
           }
         }
         __syncthreads();
-        block_chol_invert(Rl, Ril, m, &s_fail[bi]);
+        block_chol_invert_mfma(Rl, Ril, m, &s_fail[bi]);
         // panel_u = [ -Ri*T | Ri ]: tiles (row tile it, chain tile kc), A = -Ri from LDS, B = T from the scratch slice
         {
           for (int e = wid; e < MT * nkt; e += NW) {

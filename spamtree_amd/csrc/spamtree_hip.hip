@@ -695,6 +695,127 @@ __device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm
   }
 }
 
+
+// wave_chol_eliminate for a 16 x 16 (or smaller) diagonal tile that sits inside a larger matrix: strides as parameters.
+//   Am: tile's first element, row stride lda, lower triangle valid.  Bm: receives L^{-1} (lower triangle), row stride ldb.
+//   mr <= 16 rows; rows >= mr behave as identity and are not written.  All 64 lanes must call.
+__device__ __forceinline__ void wave_chol_eliminate_tile(const double *Am, int lda, double *Bm, int ldb, int mr, int *fail, int lane) {
+  constexpr int MM = 16;
+  double a[MM], b[MM];
+  const bool row = lane < mr;
+  const int lr = min(lane, MM - 1);
+#pragma unroll
+  for (int j = 0; j < MM; ++j) {
+    a[j] = (row && j <= lane) ? Am[(size_t)lr * lda + j] : (j == lane ? 1.0 : 0.0);
+    b[j] = j == lane ? 1.0 : 0.0;
+  }
+  double dd = 1.0;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < MM; ++k) {
+    if (k < mr) {   // wave-uniform
+      const double d = readlane_f64(a[k], k);
+      bad = bad || !(d > 0.0);
+      dd = lane == k ? d : dd;
+      double rd = __builtin_amdgcn_rcp(d);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      rd = fma(fma(-d, rd, 1.0), rd, rd);
+      const double f = lane > k ? -a[k] * rd : 0.0;
+#pragma unroll
+      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
+#pragma unroll
+      for (int j = 0; j < MM; ++j)
+        if (j <= k) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
+    }
+  }
+  if (bad && lane == 0) *fail = 1;
+  const double rs = rsqrt(dd);
+  if (row) {
+#pragma unroll
+    for (int j = 0; j < MM; ++j)
+      if (j <= lane) Bm[(size_t)lane * ldb + j] = b[j] * rs;
+  }
+}
+
+// Ri = chol(A)^{-1} (same contract as block_chol_invert: m x m in LDS, row stride m, lower triangle of A valid, A destroyed,
+// *fail set when a pivot is not > 0, all threads must call, Ri must not alias A) as a BLOCKED factorisation on 16 x 16 tiles:
+// per block column, the diagonal tile's inverse Cholesky factor X_kk by one wave in registers (wave_chol_eliminate_tile), the
+// panel L_ik = A_ik X_kk' and the trailing update A_ij -= L_ik L_jk' on the FP64 matrix cores (tiles dealt over the waves);
+// then the inverse by block sub-diagonals, Ri_ij = -X_ii sum_k L_ik Ri_kj.  3 barriers per block column + 1 per sub-diagonal:
+// 19 for a 75 x 75 matrix, against one per PIVOT (75) of block_chol_invert, whose 8-wave barrier round trips were 23 % of a
+// 75-column reference level of config #4.  Entries above the diagonal of Ri are zero.
+__device__ void block_chol_invert_mfma(double *A, double *Ri, int m, int *fail) {
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int nt = (m + 15) >> 4;
+  for (int idx = tid; idx < m * m; idx += blockDim.x) Ri[idx] = 0.0;
+  __syncthreads();
+  auto ld = [&](const double *M_, int r, int c) -> double { return (r < m && c < m) ? M_[(size_t)r * m + c] : 0.0; };
+  for (int kb = 0; kb < nt; ++kb) {
+    const int k0 = 16 * kb;
+    if (wid == 0) wave_chol_eliminate_tile(A + (size_t)k0 * m + k0, m, Ri + (size_t)k0 * m + k0, m, min(16, m - k0), fail, lane);
+    __syncthreads();
+    // panel: L_ik = A_ik X_kk'  (B operand: X_kk'[k][n] = X_kk[n][k]; above its diagonal Ri is zero)
+    for (int ib = kb + 1 + wid; ib < nt; ib += nw) {
+      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ld(A, 16 * ib + l15, k0 + 4 * s2 + l4), ld(Ri, k0 + l15, k0 + 4 * s2 + l4), c, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ib + 4 * q + l4, cc = k0 + l15;
+        if (r < m && cc < m) A[(size_t)r * m + cc] = c[q];
+      }
+    }
+    __syncthreads();
+    // trailing update: A_ij -= L_ik L_jk' for kb < jb <= ib
+    {
+      const int nr = nt - kb - 1, npair = nr * (nr + 1) / 2;
+      for (int e = wid; e < npair; e += nw) {
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+        const int jj = e - ii * (ii + 1) / 2;
+        const int ib = kb + 1 + ii, jb = kb + 1 + jj;
+        d4 c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = ld(A, 16 * ib + 4 * q + l4, 16 * jb + l15);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-ld(A, 16 * ib + l15, k0 + 4 * s2 + l4), ld(A, 16 * jb + l15, k0 + 4 * s2 + l4), c, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (ib == jb: the tile is both an operand source row block and the target)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 16 * ib + 4 * q + l4, cc = 16 * jb + l15;
+          if (r < m && cc < m) A[(size_t)r * m + cc] = c[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // A now holds L_ik below the block diagonal, Ri's diagonal tiles X_kk.  Ri_ij = -X_ii sum_{k = j}^{i-1} L_ik Ri_kj
+  for (int d = 1; d < nt; ++d) {
+    for (int jb = wid; jb + d < nt; jb += nw) {
+      const int ib = jb + d;
+      d4 w = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int kb = jb; kb < ib; ++kb) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+          w = __builtin_amdgcn_mfma_f64_16x16x4f64(ld(A, 16 * ib + l15, 16 * kb + 4 * s2 + l4), ld(Ri, 16 * kb + 4 * s2 + l4, 16 * jb + l15), w, 0, 0, 0);
+      }
+      d4 r4 = (d4){0.0, 0.0, 0.0, 0.0};   // the accumulator layout of W is the B-operand layout of its four K-steps
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2)
+        r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ld(Ri, 16 * ib + l15, 16 * ib + 4 * s2 + l4), w[s2], r4, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * ib + 4 * q + l4, cc = 16 * jb + l15;
+        if (r < m && cc < m) Ri[(size_t)r * m + cc] = r4[q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 #ifdef FM_STAMPS
 // diagnostic build only (never shipped): per-section shader-clock totals of k_factor_mfma, thread 0 of every workgroup
 __device__ unsigned long long g_stamps[16];
