@@ -744,27 +744,31 @@ __device__ __forceinline__ void wave_chol_eliminate_tile(const double *Am, int l
 // then the inverse by block sub-diagonals, Ri_ij = -X_ii sum_k L_ik Ri_kj.  3 barriers per block column + 1 per sub-diagonal:
 // 19 for a 75 x 75 matrix, against one per PIVOT (75) of block_chol_invert, whose 8-wave barrier round trips were 23 % of a
 // 75-column reference level of config #4.  Entries above the diagonal of Ri are zero.
-__device__ void block_chol_invert_mfma(double *A, double *Ri, int m, int *fail) {
+// the factorisation half of block_chol_invert_mfma: on return A (row stride lda) holds L_ik in its tiles below the block
+// diagonal and X (row stride ldx; may be A itself: X_kk then replaces the lower triangle of A's diagonal tile) holds
+// X_kk = L_kk^{-1} in the lower triangles of its diagonal tiles.  All threads of the block must call.
+__device__ __forceinline__ void block_chol_factor_mfma(double *A, int lda, double *X, int ldx, int m, int *fail) {
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
   const int nt = (m + 15) >> 4;
-  for (int idx = tid; idx < m * m; idx += blockDim.x) Ri[idx] = 0.0;
-  __syncthreads();
-  auto ld = [&](const double *M_, int r, int c) -> double { return (r < m && c < m) ? M_[(size_t)r * m + c] : 0.0; };
+  auto la = [&](int r, int c) -> double { return (r < m && c < m) ? A[(size_t)r * lda + c] : 0.0; };
   for (int kb = 0; kb < nt; ++kb) {
     const int k0 = 16 * kb;
-    if (wid == 0) wave_chol_eliminate_tile(A + (size_t)k0 * m + k0, m, Ri + (size_t)k0 * m + k0, m, min(16, m - k0), fail, lane);
+    if (wid == 0) wave_chol_eliminate_tile(A + (size_t)k0 * lda + k0, lda, X + (size_t)k0 * ldx + k0, ldx, min(16, m - k0), fail, lane);
     __syncthreads();
-    // panel: L_ik = A_ik X_kk'  (B operand: X_kk'[k][n] = X_kk[n][k]; above its diagonal Ri is zero)
+    // panel: L_ik = A_ik X_kk'  (B operand: X_kk'[k][n] = X_kk[n][k], lower triangular)
     for (int ib = kb + 1 + wid; ib < nt; ib += nw) {
       d4 c = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ld(A, 16 * ib + l15, k0 + 4 * s2 + l4), ld(Ri, k0 + l15, k0 + 4 * s2 + l4), c, 0, 0, 0);
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int xr = k0 + l15, xc = k0 + 4 * s2 + l4;
+        const double xb = (xr < m && xc <= xr) ? X[(size_t)xr * ldx + xc] : 0.0;
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(la(16 * ib + l15, k0 + 4 * s2 + l4), xb, c, 0, 0, 0);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 16 * ib + 4 * q + l4, cc = k0 + l15;
-        if (r < m && cc < m) A[(size_t)r * m + cc] = c[q];
+        if (r < m && cc < m) A[(size_t)r * lda + cc] = c[q];
       }
     }
     __syncthreads();
@@ -778,20 +782,29 @@ __device__ void block_chol_invert_mfma(double *A, double *Ri, int m, int *fail) 
         const int ib = kb + 1 + ii, jb = kb + 1 + jj;
         d4 c;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = ld(A, 16 * ib + 4 * q + l4, 16 * jb + l15);
+        for (int q = 0; q < 4; ++q) c[q] = la(16 * ib + 4 * q + l4, 16 * jb + l15);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2)
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-ld(A, 16 * ib + l15, k0 + 4 * s2 + l4), ld(A, 16 * jb + l15, k0 + 4 * s2 + l4), c, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (ib == jb: the tile is both an operand source row block and the target)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-la(16 * ib + l15, k0 + 4 * s2 + l4), la(16 * jb + l15, k0 + 4 * s2 + l4), c, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int r = 16 * ib + 4 * q + l4, cc = 16 * jb + l15;
-          if (r < m && cc < m) A[(size_t)r * m + cc] = c[q];
+          if (r < m && cc < m) A[(size_t)r * lda + cc] = c[q];
         }
       }
     }
     __syncthreads();
   }
+}
+
+__device__ void block_chol_invert_mfma(double *A, double *Ri, int m, int *fail) {
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+  const int nt = (m + 15) >> 4;
+  for (int idx = tid; idx < m * m; idx += blockDim.x) Ri[idx] = 0.0;
+  __syncthreads();
+  auto ld = [&](const double *M_, int r, int c) -> double { return (r < m && c < m) ? M_[(size_t)r * m + c] : 0.0; };
+  block_chol_factor_mfma(A, m, Ri, m, m, fail);
   // A now holds L_ik below the block diagonal, Ri's diagonal tiles X_kk.  Ri_ij = -X_ii sum_{k = j}^{i-1} L_ik Ri_kj
   for (int d = 1; d < nt; ++d) {
     for (int jb = wid; jb + d < nt; jb += nw) {
@@ -814,6 +827,55 @@ __device__ void block_chol_invert_mfma(double *A, double *Ri, int m, int *fail) 
     }
     __syncthreads();
   }
+}
+
+
+// w = L^{-T} (L^{-1} b + z), S = L L' (m x m in LDS, row stride lds_, lower triangle valid, destroyed), for 33..80-row blocks, by
+// the whole workgroup: the blocked factorisation above with X_kk stored over S's own diagonal tiles, then block forward and
+// backward substitutions -- thread i owns row i; a block step is one 16 x 16 triangular product with X_kk (through `vec`, m
+// doubles of LDS) and one rank-16 update of the rows below / above.  About 35 barriers of four waves and five one-wave 16 x 16
+// eliminations, against the 75 dependent pivots of wave_chol_solve_lds.  bv (LDS): in b, out w.  All threads must call.
+__device__ void block_chol_solve_mfma(double *S, int lds_, double *vec, double *bv, const double *zg, int m, int *fail) {
+  const int tid = threadIdx.x;
+  const int nt = (m + 15) >> 4;
+  block_chol_factor_mfma(S, lds_, S, lds_, m, fail);
+  const int i = tid, ib = tid >> 4;           // row i (tid < m)
+  const bool rowok = i < m;
+  double r = rowok ? bv[i] : 0.0;
+  for (int kb = 0; kb < nt; ++kb) {           // forward: y_k = X_kk r_k, then r_i -= L_ik y_k for the rows below
+    const int k0 = 16 * kb, k1 = min(m, k0 + 16);
+    if (rowok && ib == kb) vec[i] = r;
+    __syncthreads();
+    double y = 0.0;
+    if (rowok && ib == kb) {
+      for (int c = k0; c <= i; ++c) y += S[(size_t)i * lds_ + c] * vec[c];
+    }
+    __syncthreads();
+    if (rowok && ib == kb) { vec[i] = y; r = y; }
+    __syncthreads();
+    if (rowok && ib > kb) {
+      for (int c = k0; c < k1; ++c) r -= S[(size_t)i * lds_ + c] * vec[c];
+    }
+  }
+  double t = rowok ? r + zg[i] : 0.0;         // r = y = L^{-1} b
+  for (int kb = nt - 1; kb >= 0; --kb) {      // backward: w_k = X_kk' t_k, then t_i -= L_ki' w_k for the rows above
+    const int k0 = 16 * kb, k1 = min(m, k0 + 16);
+    __syncthreads();
+    if (rowok && ib == kb) vec[i] = t;
+    __syncthreads();
+    double w = 0.0;
+    if (rowok && ib == kb) {
+      for (int c = i; c < k1; ++c) w += S[(size_t)c * lds_ + i] * vec[c];
+    }
+    __syncthreads();
+    if (rowok && ib == kb) { vec[i] = w; t = w; }
+    __syncthreads();
+    if (rowok && ib < kb) {
+      for (int c = k0; c < k1; ++c) t -= S[(size_t)c * lds_ + i] * vec[c];
+    }
+  }
+  if (rowok) bv[i] = t;
+  __syncthreads();
 }
 
 #ifdef FM_STAMPS
@@ -1368,7 +1430,9 @@ struct SampleArgs {
   double tausq_inv[QMAX];
 };
 
-template <bool BIG>
+// NOREF: the level holds non-reference blocks only (the host knows): the reference branch -- whose blocked factorisation takes
+// 224 VGPRs -- is compiled out, so that leaf levels keep four waves per SIMD
+template <bool BIG, bool NOREF = false>
 __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
@@ -1441,7 +1505,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     __syncthreads();
 
     STAMP(0);
-    if (B.isref) {
+    if (!NOREF && B.isref) {
       const double *Ri = N + P;  // Ri[i][j] = N[i*ld + P + j]
       // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
       const int ms = (BIG && A.lds_sq) ? ((m + 7) | 1) : m;   // row stride of S
@@ -1492,7 +1556,8 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         STAMP(1);
         // (Np, not S: S is `lds_sq ? LDS : scratch arena`, a generic pointer -- the compiler would emit FLAT loads and stores,
         // six times slower than ds_read / ds_write here)
-        if (wid == 0) wave_chol_solve_lds(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail, lane);
+        if (m > 32) block_chol_solve_mfma(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail);   // (workgroup-uniform)
+        else if (wid == 0) wave_chol_solve_lds(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail, lane);
       } else {
       chol_lower_inplace(S, m, &s_fail);
       // w_u = L^{-T} (L^{-1} Smu + z)   (= Sigi_chol' (Sigi_chol Smu + z), :1086)
@@ -3435,7 +3500,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     L.big_factor = h->force_generic || L.lds_factor > h->lds_limit;
     if (L.big_factor) L.lds_factor = lds_factor_bytes(L.maxP, L.maxM, L.maxMa, 4, true);
     L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, false);
-    L.big_sample = h->force_generic || L.lds_sample > h->lds_limit;
+    L.big_sample = h->force_generic || L.lds_sample > h->lds_limit || (L.isref && L.maxM > 32 && L.maxM <= 80);   // wide reference blocks: the
+    // scratch-arena kernel has the blocked matrix-core solve (the LDS-panel kernel factorises with three barriers per pivot)
     if (L.big_sample) {
       L.lds_sample = lds_sample_bytes(L.maxP, L.maxM, L.maxLd, true);
       // the posterior precision in LDS, factorised and solved by ONE wave without workgroup barriers (wave_chol_solve_lds):
@@ -3937,6 +4003,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_factor<true, MODE_PREDICT>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_sample<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_loglik, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_factor_wide<WG_JT>, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -4600,7 +4667,8 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         }
         if (L.big_sample) {
           A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
-          hipLaunchKernelGGL((k_sample<true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
+          if (L.isref) hipLaunchKernelGGL((k_sample<true, false>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
+          else hipLaunchKernelGGL((k_sample<true, true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
         } else {
           hipLaunchKernelGGL((k_sample<false>), dim3(L.own_n), dim3(NT), L.lds_sample, h->stream, A);
         }
