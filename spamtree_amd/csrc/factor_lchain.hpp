@@ -219,153 +219,243 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
 
   STAMP(1);
 #define LCMFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, c_, 0, 0, 0)
-  // ---- phase 1: V_r = Linv[r, 0 .. r] K, last tile first; V_r replaces kx[4 r .. 4 r + 3]
   double dacc = 0.0;   // sum_k V[k][column l15]^2 over this lane's rows
-  {
-    int cur = 0;
+  double rj = 0.0, rq[4] = {0.0, 0.0, 0.0, 0.0};
+  double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;   // hv = T w_pa for columns 4 q + l4, this lane's chain columns
+  if (isload && JTb < 4) {
+    // ---- a LOADER wave (no columns): both phases as ROLLED loops of their own -- it needs no static tile index -- that meet the
+    // column waves at the same barriers.  What bounds a step is this wave's round trip (request, flight, padding), not the
+    // matrix work: without a single MFMA the kernel took 70 % of its time.  The requests therefore take their table entries four
+    // rows / eight row groups at a time (one LDS latency per batch instead of one per row).
+    auto fire1 = [&](int r, double *buf) {
+      for (int row0 = lidx; row0 < 16; row0 += 4 * nload) {
+        int ln[4];
+        const double *src[4];
 #pragma unroll
-    for (int r = NTMAX - 1; r >= 0; --r) {
-      if (r < NTL) {   // workgroup-uniform
-        double *buf = lds + (size_t)cur * B1;
-        if (isload) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile r have landed
-          for (int row = lidx; row < 16; row += nload) {
-            const int c = 16 * r + row;
-            if (c < P) {
-              const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
-              // the tile reads columns < 16 (r + 1) only; zero from the row's own end (what was fetched past it)
-              if (len + lane < 16 * (r + 1)) buf[(size_t)row * ldS + len + lane] = 0.0;
-            } else {
-              for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;   // rows beyond the chain (last tile)
+        for (int j = 0; j < 4; ++j) {
+          const int c = min(16 * r + min(row0 + j * nload, 15), P - 1);
+          ln[j] = s_rlen[c];
+          src[j] = A.panels + s_rsrc[c] + 2 * lane;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = row0 + j * nload;
+          if (row < 16) {
+            const int lu = min(__builtin_amdgcn_readfirstlane(ln[j]), 16 * (r + 1));
+            q_lds_void *dst = (q_lds_void *)(buf + (size_t)row * ldS);
+            q_glb_void *sp = (q_glb_void *)src[j];
+            __builtin_amdgcn_global_load_lds(sp, dst, 16, 0, 0);
+            if (lu > 128) __builtin_amdgcn_global_load_lds(sp, dst, 16, 1024, 0);
+            if (lu > 256) __builtin_amdgcn_global_load_lds(sp, dst, 16, 2048, 0);
+            if (lu > 384) __builtin_amdgcn_global_load_lds(sp, dst, 16, 3072, 0);
+            if (lu > 512) {
+              if (512 + 2 * lane < lu)
+                __builtin_amdgcn_global_load_lds((q_glb_void *)(src[j] + 512), (q_lds_void *)(buf + (size_t)row * ldS + 512), 16, 0, 0);
             }
           }
         }
-        STAMP(2);
-        lds_barrier();
-        STAMP(3);
-        if (r > 0 && isload) issue1(r - 1, lds + (size_t)(cur ^ 1) * B1);
-        STAMP(4);
-        if (wact) {
-          d4 p = (d4){0.0, 0.0, 0.0, 0.0};
-          const double *ap = buf + l15 * ldS + l4;
-#pragma unroll
-          for (int st = 0; st < 4 * (r + 1); ++st)
-            if (st < NKX) LCMFMA(ap[4 * st], kx[st], p);
-          dacc += p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (4 * r + q < NKX) kx[4 * r + q] = p[q];
-        }
-        STAMP(5);
-        cur ^= 1;
       }
-    }
-  }
-  lds_barrier();   // phase 2 reuses the buffers
-  STAMP(6);
-
-  // ---- r_j = 1 / sqrt(K_jj - sum_k V_kj^2)  (spamtree_model.cpp:944-951)
-  double rj = 0.0;
-  {
-    double dsum = dacc;
-    dsum += __shfl_xor(dsum, 16, 64);
-    dsum += __shfl_xor(dsum, 32, 64);
-    if (cok) {
-      const double d = (qn == 1 ? lc_cov<false>(s_cpt, qn, s2, nphi, mx, my, mvj, mx, my, mvj) : lc_cov<true>(s_cpt, qn, s2, nphi, mx, my, mvj, mx, my, mvj)) - dsum;
-      if (!(d > 0.0)) s_fail = 1;
-      rj = 1.0 / sqrt(d);
-    }
-  }
-  double rq[4];   // r of column 16 wid + 4 q + l4 (lane (0, column) holds that column's r)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) rq[q] = __shfl(rj, l4 + 4 * q, 64);
-
-  // ---- phase 2: T[:, kt] = sum_{r >= kt} V_r' Linv[r, kt]; column block kt of Linv = chain rows [16 kt, P) x 16 columns,
-  // row c at offset c * 16 of the buffer (static operand offsets); one LDS-DMA instruction moves 8 rows (8 lanes x 16 B each)
-  auto issue2 = [&](int kt, double *buf) {   // 8-row group g belongs to loader g % nload
-    const int g1 = (P + 7) >> 3, g0 = 2 * kt;
-    const int koff = 16 * kt + 2 * (lane & 7);
-    int g = g0 + lidx - (g0 % nload);
-    if (g < g0) g += nload;
-    for (; g < g1; g += nload) {   // rows beyond the chain: any row (their V rows are zero)
-      const double *rp = A.panels + s_rsrc[min(8 * g + (lane >> 3), P - 1)] + koff;
-      __builtin_amdgcn_global_load_lds((q_glb_void *)rp, (q_lds_void *)(buf + (size_t)g * 128), 16, 0, 0);
-    }
-  };
-  double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;   // hv = T w_pa for columns 4 q + l4, this lane's chain columns
-  {
-    double *pu = A.panels + S.pan0;
-    const int ld = S.ld;
-    if (isload) issue2(0, lds);
+    };
     int cur = 0;
+    for (int r = NTL - 1; r >= 0; --r) {
+      double *buf = lds + (size_t)cur * B1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int row = lidx; row < 16; row += nload) {
+        const int c = 16 * r + row;
+        if (c < P) {
+          const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
+          if (len + lane < 16 * (r + 1)) buf[(size_t)row * ldS + len + lane] = 0.0;
+        } else {
+          for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;
+        }
+      }
+      lds_barrier();
+      if (r > 0) fire1(r - 1, lds + (size_t)(cur ^ 1) * B1);
+      cur ^= 1;
+    }
+    lds_barrier();   // phase boundary
+    auto fire2 = [&](int kt, double *buf) {   // 8-row group g belongs to loader g % nload; eight groups per trip
+      const int g1 = (P + 7) >> 3, g0 = 2 * kt;
+      const int koff = 16 * kt + 2 * (lane & 7);
+      int g = g0 + lidx - (g0 % nload);
+      if (g < g0) g += nload;
+      for (; g < g1; g += 8 * nload) {
+        long long so[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) so[e] = s_rsrc[min(8 * min(g + e * nload, g1 - 1) + (lane >> 3), P - 1)];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ge = g + e * nload;
+          if (ge < g1)
+            __builtin_amdgcn_global_load_lds((q_glb_void *)(A.panels + so[e] + koff), (q_lds_void *)(buf + (size_t)ge * 128), 16, 0, 0);
+        }
+      }
+    };
+    fire2(0, lds);
+    cur = 0;
     for (int kt = 0; kt < NTL; ++kt) {
       double *buf = lds + (size_t)cur * B2;
-      if (isload) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // the diagonal tile's entries above the diagonal are structural zeros, but rows that END inside this column block were
-        // fetched past their end: wipe (the loader of the 8-row group does it, after its own data has landed)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int g = 2 * kt + hh;
-          if (lidx == g % nload) {
-            const int i = 8 * hh + (lane >> 3), j0 = 2 * (lane & 7);
-            double *e = buf + (size_t)(16 * kt + i) * 16 + j0;
-            if (j0 > i) e[0] = 0.0;
-            if (j0 + 1 > i) e[1] = 0.0;
-          }
+      for (int hh = 0; hh < 2; ++hh) {
+        const int g = 2 * kt + hh;
+        if (lidx == g % nload) {
+          const int i = 8 * hh + (lane >> 3), j0 = 2 * (lane & 7);
+          double *e = buf + (size_t)(16 * kt + i) * 16 + j0;
+          if (j0 > i) e[0] = 0.0;
+          if (j0 + 1 > i) e[1] = 0.0;
         }
       }
-      STAMP(7);
       lds_barrier();
-      STAMP(8);
-      if (kt + 1 < NTL && isload) issue2(kt + 1, lds + (size_t)(cur ^ 1) * B2);
-      STAMP(9);
-      if (wact) {
-        d4 t = (d4){0.0, 0.0, 0.0, 0.0};
-        const double *bp = buf + l4 * 16 + l15;
-        // the B operands of row tile r + 1 are requested BEFORE the MFMAs of row tile r (two register sets, taken in turn; a
-        // scheduling barrier keeps the requests in front): every row tile is a basic block of its own (skipped for r < kt),
-        // and the compiler neither moves loads across those nor hoists them above MFMAs that still read the same registers
-        double b0[4], b1[4];
-        if (kt & 1) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { b1[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b0[q] = 0.0; }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { b0[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b1[q] = 0.0; }
-        }
-#pragma unroll
-        for (int r = 0; r < NTMAX; ++r) {
-          // (a computed entry -- switch (kt) with fall-through cases -- would save the compare + branch of every skipped tile,
-          // but the register allocator then needs > 512 VGPRs: measured, dropped)
-          if (r >= kt && r < NTL) {   // workgroup-uniform
-            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this tile's operands (requested one tile ago) are here; said
-                                                  // explicitly (and visibly to the compiler), or it waits AFTER the new requests
-            if (r + 1 < NTMAX) {      // inside the buffer (B2 holds PMAX + 16 rows)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                if ((r & 1) == 0) b1[q] = bp[(16 * (r + 1) + 4 * q) * 16]; else b0[q] = bp[(16 * (r + 1) + 4 * q) * 16];
+      if (kt + 1 < NTL) fire2(kt + 1, lds + (size_t)(cur ^ 1) * B2);
+      cur ^= 1;
+    }
+  } else {
+    // ---- phase 1: V_r = Linv[r, 0 .. r] K, last tile first; V_r replaces kx[4 r .. 4 r + 3]
+    {
+      int cur = 0;
+  #pragma unroll
+      for (int r = NTMAX - 1; r >= 0; --r) {
+        if (r < NTL) {   // workgroup-uniform
+          double *buf = lds + (size_t)cur * B1;
+          if (isload) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile r have landed
+            for (int row = lidx; row < 16; row += nload) {
+              const int c = 16 * r + row;
+              if (c < P) {
+                const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
+                // the tile reads columns < 16 (r + 1) only; zero from the row's own end (what was fetched past it)
+                if (len + lane < 16 * (r + 1)) buf[(size_t)row * ldS + len + lane] = 0.0;
+              } else {
+                for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;   // rows beyond the chain (last tile)
               }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
+          }
+          STAMP(2);
+          lds_barrier();
+          STAMP(3);
+          if (r > 0 && isload) issue1(r - 1, lds + (size_t)(cur ^ 1) * B1);
+          STAMP(4);
+          if (wact) {
+            d4 p = (d4){0.0, 0.0, 0.0, 0.0};
+            const double *ap = buf + l15 * ldS + l4;
+  #pragma unroll
+            for (int st = 0; st < 4 * (r + 1); ++st)
+              if (st < NKX) LCMFMA(ap[4 * st], kx[st], p);
+            dacc += p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
+  #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (4 * r + q < NKX) LCMFMA(kx[4 * r + q], (r & 1) == 0 ? b0[q] : b1[q], t);
+              if (4 * r + q < NKX) kx[4 * r + q] = p[q];
           }
-        }
-        const int k = 16 * kt + l15;
-        if (k < P) {
-          const double wv = s_wpa[k];
-          h0 = fma(t[0], wv, h0); h1 = fma(t[1], wv, h1); h2 = fma(t[2], wv, h2); h3 = fma(t[3], wv, h3);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int j = 16 * wid + 4 * q + l4;
-            if (j < m) pu[(size_t)j * ld + k] = -rq[q] * t[q];
-          }
+          STAMP(5);
+          cur ^= 1;
         }
       }
-      STAMP(10);
-      cur ^= 1;
+    }
+    lds_barrier();   // phase 2 reuses the buffers
+    STAMP(6);
+
+    // ---- r_j = 1 / sqrt(K_jj - sum_k V_kj^2)  (spamtree_model.cpp:944-951)
+    {
+      double dsum = dacc;
+      dsum += __shfl_xor(dsum, 16, 64);
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (cok) {
+        const double d = (qn == 1 ? lc_cov<false>(s_cpt, qn, s2, nphi, mx, my, mvj, mx, my, mvj) : lc_cov<true>(s_cpt, qn, s2, nphi, mx, my, mvj, mx, my, mvj)) - dsum;
+        if (!(d > 0.0)) s_fail = 1;
+        rj = 1.0 / sqrt(d);
+      }
+    }
+    // rq[q]: r of column 16 wid + 4 q + l4 (lane (0, column) holds that column's r)
+  #pragma unroll
+    for (int q = 0; q < 4; ++q) rq[q] = __shfl(rj, l4 + 4 * q, 64);
+
+    // ---- phase 2: T[:, kt] = sum_{r >= kt} V_r' Linv[r, kt]; column block kt of Linv = chain rows [16 kt, P) x 16 columns,
+    // row c at offset c * 16 of the buffer (static operand offsets); one LDS-DMA instruction moves 8 rows (8 lanes x 16 B each)
+    auto issue2 = [&](int kt, double *buf) {   // 8-row group g belongs to loader g % nload
+      const int g1 = (P + 7) >> 3, g0 = 2 * kt;
+      const int koff = 16 * kt + 2 * (lane & 7);
+      int g = g0 + lidx - (g0 % nload);
+      if (g < g0) g += nload;
+      for (; g < g1; g += nload) {   // rows beyond the chain: any row (their V rows are zero)
+        const double *rp = A.panels + s_rsrc[min(8 * g + (lane >> 3), P - 1)] + koff;
+        __builtin_amdgcn_global_load_lds((q_glb_void *)rp, (q_lds_void *)(buf + (size_t)g * 128), 16, 0, 0);
+      }
+    };
+    {
+      double *pu = A.panels + S.pan0;
+      const int ld = S.ld;
+      if (isload) issue2(0, lds);
+      int cur = 0;
+      for (int kt = 0; kt < NTL; ++kt) {
+        double *buf = lds + (size_t)cur * B2;
+        if (isload) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // the diagonal tile's entries above the diagonal are structural zeros, but rows that END inside this column block were
+          // fetched past their end: wipe (the loader of the 8-row group does it, after its own data has landed)
+  #pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const int g = 2 * kt + hh;
+            if (lidx == g % nload) {
+              const int i = 8 * hh + (lane >> 3), j0 = 2 * (lane & 7);
+              double *e = buf + (size_t)(16 * kt + i) * 16 + j0;
+              if (j0 > i) e[0] = 0.0;
+              if (j0 + 1 > i) e[1] = 0.0;
+            }
+          }
+        }
+        STAMP(7);
+        lds_barrier();
+        STAMP(8);
+        if (kt + 1 < NTL && isload) issue2(kt + 1, lds + (size_t)(cur ^ 1) * B2);
+        STAMP(9);
+        if (wact) {
+          d4 t = (d4){0.0, 0.0, 0.0, 0.0};
+          const double *bp = buf + l4 * 16 + l15;
+          // the B operands of row tile r + 1 are requested BEFORE the MFMAs of row tile r (two register sets, taken in turn; a
+          // scheduling barrier keeps the requests in front): every row tile is a basic block of its own (skipped for r < kt),
+          // and the compiler neither moves loads across those nor hoists them above MFMAs that still read the same registers
+          double b0[4], b1[4];
+          if (kt & 1) {
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) { b1[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b0[q] = 0.0; }
+          } else {
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) { b0[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b1[q] = 0.0; }
+          }
+  #pragma unroll
+          for (int r = 0; r < NTMAX; ++r) {
+            // (a computed entry -- switch (kt) with fall-through cases -- would save the compare + branch of every skipped tile,
+            // but the register allocator then needs > 512 VGPRs: measured, dropped)
+            if (r >= kt && r < NTL) {   // workgroup-uniform
+              __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this tile's operands (requested one tile ago) are here; said
+                                                    // explicitly (and visibly to the compiler), or it waits AFTER the new requests
+              if (r + 1 < NTMAX) {      // inside the buffer (B2 holds PMAX + 16 rows)
+  #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  if ((r & 1) == 0) b1[q] = bp[(16 * (r + 1) + 4 * q) * 16]; else b0[q] = bp[(16 * (r + 1) + 4 * q) * 16];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (4 * r + q < NKX) LCMFMA(kx[4 * r + q], (r & 1) == 0 ? b0[q] : b1[q], t);
+            }
+          }
+          const int k = 16 * kt + l15;
+          if (k < P) {
+            const double wv = s_wpa[k];
+            h0 = fma(t[0], wv, h0); h1 = fma(t[1], wv, h1); h2 = fma(t[2], wv, h2); h3 = fma(t[3], wv, h3);
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int j = 16 * wid + 4 * q + l4;
+              if (j < m) pu[(size_t)j * ld + k] = -rq[q] * t[q];
+            }
+          }
+        }
+        STAMP(10);
+        cur ^= 1;
+      }
     }
   }
 #undef LCMFMA
