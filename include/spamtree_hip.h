@@ -115,6 +115,12 @@ int st_loglik_w(st_handle h, int slot, double *loglik);
 /* st_sample_w followed by st_loglik_w(slot), same results and return codes (the sweep's 10 / 11 first), with a single
  * host synchronisation: what the MCMC driver calls once per iteration (spamtree_fit.cpp:182-185). */
 int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot, double *loglik);
+/* The same pair without its host synchronisation (spamtree_fit.cpp:182-185 then :211-289: the sweep's log-density is not read
+ * before the Metropolis step): _begin enqueues sweep + phase C and returns; any later synchronising call (st_factor) brings the
+ * results along; _end returns what st_sample_w_loglik would have (0 and *loglik, or the sweep's failure code 10 / 11).  One
+ * _end per _begin, before the next sweep.  Multi-GPU handles run the synchronous protocol inside _begin. */
+int st_sample_w_loglik_begin(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot);
+int st_sample_w_loglik_end(st_handle h, double *loglik);
 
 /* ---- phase P: predict_std(true, theta_changed) on param_data (spamtree_model.cpp:1234-1358); uses the last sweep's z */
 int st_predict(st_handle h, int theta_changed);

@@ -41,6 +41,8 @@ SIGNATURES = {
     "st_sample_w": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32]),
     "st_loglik_w": (C.c_int, [H, C.c_int, c_dp]),
     "st_sample_w_loglik": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32, C.c_int, c_dp]),
+    "st_sample_w_loglik_begin": (C.c_int, [H, c_dp, C.c_uint64, C.c_uint32, C.c_int]),
+    "st_sample_w_loglik_end": (C.c_int, [H, c_dp]),
     "st_predict": (C.c_int, [H, C.c_int]),
     "st_beta_stats": (C.c_int, [H, c_dp]),
     "st_tausq_stats": (C.c_int, [H, c_dp, c_ip]),

@@ -11,6 +11,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -248,16 +249,32 @@ static int step_w_theta(stm_chain c) {
       if (rc < 0) { c->err = st_last_error(c->h); return rc; }
     }
   }
-  if (c->sample_w) {
-    rc = st_sample_w_loglik(c->h, nullptr, c->seed, m, 0, &c->loglik[0]);   // deal_with_w + get_loglik_w (:182-185)
-    if (rc > 0) { c->err = "Error at gibbs_sample_w"; return rc; }
-    if (rc < 0) { c->err = st_last_error(c->h); return rc; }
+  // deal_with_w + get_loglik_w (:182-185).  The sweep's log-density is first read in the Metropolis step below: when a
+  // proposal follows, sweep and phase C are only ENQUEUED here and their results come along with the synchronisation at the end
+  // of the proposal's factorisation (one host round trip and one idle gap of the GPU less per iteration)
+  bool sweep_open = false;
+  auto finish_sweep = [&]() -> int {
+    const int r2 = st_sample_w_loglik_end(c->h, &c->loglik[0]);
+    if (r2 > 0) { c->err = "Error at gibbs_sample_w"; return r2; }
+    if (r2 < 0) { c->err = st_last_error(c->h); return r2; }
     c->current_loglik = c->loglik[0];
+    return 0;
+  };
+  if (c->sample_w) {
+    rc = st_sample_w_loglik_begin(c->h, nullptr, c->seed, m, 0);
+    if (rc) { c->err = st_last_error(c->h); return rc; }
+    static const bool defer = !(getenv("SPAMTREE_DEFER_SYNC") && getenv("SPAMTREE_DEFER_SYNC")[0] == '0');   // 0: read the sweep's results at once
+    if ((!c->sample_theta || !defer) && (rc = finish_sweep()) != 0) return rc;
+    sweep_open = c->sample_theta && defer;
   }
   if (c->sample_theta) {
     c->theta_alt = np;
     double new_ll = c->loglik[1];
     rc = st_factor(c->h, 1, np.data(), k, &new_ll);
+    if (sweep_open) {
+      const int r2 = finish_sweep();   // (a failed sweep outranks whatever the factorisation of the proposal made of its w)
+      if (r2) return r2;
+    }
     if (rc < 0) { c->err = st_last_error(c->h); return rc; }
     const bool acceptable = rc == 0;
     if (acceptable) c->loglik[1] = new_ll;

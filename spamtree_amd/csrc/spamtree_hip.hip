@@ -3052,6 +3052,8 @@ struct st_handle_s {
   DevBuf<double> d_lcrow;                     // per-row e^2 | log r of the lchain levels (2 n)
   DevBuf<double> d_s0;                        // Ri' Ri of the reference blocks on the generic phase-B path (theta-only, cached with the Gram parts)
   DevBuf<long long> d_s0off;                  // per block: offset into d_s0, -1 = none
+  bool c_pending = false;                     // st_sample_w_loglik_begin: the sweep's failure word and log-density are on their way to pin[8..10]
+  int c_rc = 0; double c_ll = 0.0;            // ... or (multi-GPU / communicator attached) already here
   int gram_big = 1;                           // SPAMTREE_GRAM_BIG=0: the generic sweep kernel rebuilds the records' Gram parts itself (one thread per entry)
   int lchain_on = 1;                          // SPAMTREE_LCHAIN=0: non-reference long-chain levels stay on k_factor_wide / k_factor_bigmfma
   std::vector<long long> gdesc;               // group descriptors (GdHead layout), gd_stride words per group
@@ -4598,6 +4600,52 @@ extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, u
   const int e0 = ((const int *)(h->pin + 2))[0];
   if (e0 != INT_MAX) return e0 & 15;  // 10 / 11: the reference stops with "Error at gibbs_sample_w" (:1215-1217)
   if (loglik) *loglik = h->pin[0] + h->pin[1];
+  return ST_OK;
+}
+
+// The same pair WITHOUT the host synchronisation: the log-density of the sweep's w is not needed on the host before the
+// Metropolis step, i.e. after the proposal's factorisation -- whose own synchronisation then brings it along.  One round trip
+// and one idle gap of the GPU less per iteration (the driver enqueues phase A right behind phase C).  _end returns what the
+// synchronous call would have returned (failure code of the sweep / the log-density); it synchronises only if nobody has yet.
+// With a communicator attached (multi-GPU) _begin simply runs the synchronous protocol and _end hands its result over.
+extern "C" int st_sample_w_loglik_begin(st_handle h, const double *z, uint64_t seed, uint32_t iter, int slot) {
+  if (!h || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  if (h->c_pending) return ST_ERR_USAGE;
+  if (h->world > 1 || h->comm) {
+    h->c_ll = 0.0;
+    h->c_rc = st_sample_w_loglik(h, z, seed, iter, slot, &h->c_ll);
+    h->c_pending = true;
+    return h->c_rc < 0 ? h->c_rc : ST_OK;
+  }
+  int rc = st_sample_w_local(h, z, seed, iter);
+  if (rc) return rc;
+  rc = st_sample_w_top(h);
+  if (rc) return rc;
+  HCHK(h, hipMemcpyAsync(h->pin + 10, h->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  rc = st_loglik_local(h, slot);   // resets the failure word after the copy above (stream order)
+  if (rc) return rc;
+  {
+    ProfScope ps(h, 3);
+    const int phys = h->slot_map[slot];
+    launch_sum2(h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p + 8, h->d_scalars.p);
+  }
+  HCHK(h, hipGetLastError());
+  HCHK(h, hipMemcpyAsync(h->pin + 8, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  h->c_rc = INT_MIN;   // not known yet
+  h->c_pending = true;
+  return ST_OK;
+}
+extern "C" int st_sample_w_loglik_end(st_handle h, double *loglik) {
+  if (!h || !h->c_pending) return ST_ERR_USAGE;
+  h->c_pending = false;
+  if (h->c_rc != INT_MIN) {   // the synchronous protocol ran in _begin
+    if (h->c_rc == ST_OK && loglik) *loglik = h->c_ll;
+    return h->c_rc;
+  }
+  HCHK(h, hipStreamSynchronize(h->stream));   // returns at once when a later call (st_factor) has synchronised already
+  const int e0 = ((const int *)(h->pin + 10))[0];
+  if (e0 != INT_MAX) return e0 & 15;   // 10 / 11: "Error at gibbs_sample_w"
+  if (loglik) *loglik = h->pin[8] + h->pin[9];
   return ST_OK;
 }
 
