@@ -16,7 +16,8 @@ from spamtree_amd.synthetic import make_workload  # noqa: E402
 
 NAMES = {0: "topology + coords + LDS clear", 1: "covariance -> registers", 2: "phase 1: DMA wait + pad", 3: "phase 1: barrier", 4: "phase 1: DMA issue",
          5: "phase 1: V tile (MFMA)", 6: "r_j", 7: "phase 2: DMA wait + diag fix", 8: "phase 2: barrier", 9: "phase 2: DMA issue",
-         10: "phase 2: T tile (MFMA) + stores", 11: "scalars"}
+         10: "phase 2: T tile (MFMA) + stores", 11: "scalars",
+         12: "LOADER phase 1: landing wait", 13: "LOADER phase 1: padding", 14: "LOADER phase 1: barrier wait", 15: "LOADER phase 1: requests (+ loop)"}
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 577
 wl = make_workload(side, q=3)
 hm = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"], wl["res_is_ref"],

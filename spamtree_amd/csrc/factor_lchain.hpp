@@ -20,6 +20,10 @@
 // workgroup per CU; both phases double-buffer their LDS-DMA under the matrix work; one barrier per tile.
 // P <= 4 NKX, m <= 64 columns, J >= 1 ancestors (host check).  Results equal k_factor_bigmfma's up to summation order.
 #define LC_NT 256
+#ifndef LC_RSH
+#define LC_RSH 17
+#endif
+// LC_RSH: phase 1: tiles up to this index are staged by all four waves (above: by the loader waves alone)
 
 __host__ __device__ constexpr int lc_lds_stride(int nkx) {   // phase-1 row stride: >= 4 nkx + 24, 2 x odd (conflict-free A reads)
   int s = 4 * nkx + 24;
@@ -155,8 +159,11 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
   const int JTb = (m + 15) >> 4;
   const int nload = JTb < 4 ? 4 - JTb : 4, lidx = JTb < 4 ? wid - JTb : wid;
   const bool isload = lidx >= 0;
-  auto issue1 = [&](int r, double *buf) {
-    for (int row = lidx; row < 16; row += nload) {
+  // Tiles r <= LC_RSH are requested (and padded) by ALL FOUR waves, four rows each: their matrix work is shorter than one
+  // wave's sixteen rows of requests (about 2.4k cycles of table reads, address set-up and DMA issue), so the column waves
+  // would only wait for the loader at the barrier -- 14 % of their time before.
+  auto issue1 = [&](int r, double *buf, int li_, int nl_) {
+    for (int row = li_; row < 16; row += nl_) {
       const int c = min(16 * r + row, P - 1);   // rows beyond the chain (last tile): any row, zero-filled afterwards
       const int ln = min(__builtin_amdgcn_readfirstlane(s_rlen[c]), 16 * (r + 1));   // the tile reads columns < 16 (r + 1) only
       const double *srow = A.panels + s_rsrc[c] + 2 * lane;
@@ -173,7 +180,8 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
     }
   };
   STAMP(0);
-  if (isload) issue1(NTL - 1, lds);   // lands under the covariance pass
+  if (JTb == 4 || NTL - 1 <= LC_RSH) issue1(NTL - 1, lds, wid, 4);   // lands under the covariance pass
+  else if (isload) issue1(NTL - 1, lds, lidx, nload);
 
   // ---- K_{pa,u}: kx[st] = K[4 st + l4][column 16 wid + l15]  (covariance_functions.cpp:95-111 / :213-286), rolled loop
   // through lane-private LDS slots, picked up with static register indices
@@ -228,18 +236,19 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
     // matrix work: without a single MFMA the kernel took 70 % of its time.  The requests therefore take their table entries four
     // rows / eight row groups at a time (one LDS latency per batch instead of one per row).
     auto fire1 = [&](int r, double *buf) {
-      for (int row0 = lidx; row0 < 16; row0 += 4 * nload) {
+      const int li_ = r <= LC_RSH ? wid : lidx, nl_ = r <= LC_RSH ? 4 : nload;   // short tiles: this wave's quarter only
+      for (int row0 = li_; row0 < 16; row0 += 4 * nl_) {
         int ln[4];
         const double *src[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int c = min(16 * r + min(row0 + j * nload, 15), P - 1);
+          const int c = min(16 * r + min(row0 + j * nl_, 15), P - 1);
           ln[j] = s_rlen[c];
           src[j] = A.panels + s_rsrc[c] + 2 * lane;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int row = row0 + j * nload;
+          const int row = row0 + j * nl_;
           if (row < 16) {
             const int lu = min(__builtin_amdgcn_readfirstlane(ln[j]), 16 * (r + 1));
             q_lds_void *dst = (q_lds_void *)(buf + (size_t)row * ldS);
@@ -259,17 +268,30 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
     int cur = 0;
     for (int r = NTL - 1; r >= 0; --r) {
       double *buf = lds + (size_t)cur * B1;
+      STAMP(15);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      for (int row = lidx; row < 16; row += nload) {
-        const int c = 16 * r + row;
-        if (c < P) {
-          const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
-          if (len + lane < 16 * (r + 1)) buf[(size_t)row * ldS + len + lane] = 0.0;
-        } else {
-          for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;
+      STAMP(12);
+      // padding, eight rows per trip: one LDS latency per trip instead of one dependent table read per row
+      const int li_ = r <= LC_RSH ? wid : lidx, nl_ = r <= LC_RSH ? 4 : nload;
+      for (int row0 = li_; row0 < 16; row0 += 8 * nl_) {
+        int ln[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ln[j] = s_rlen[min(16 * r + min(row0 + j * nl_, 15), P - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int row = row0 + j * nl_, c = 16 * r + row;
+          if (row < 16) {
+            if (c < P) {
+              if (ln[j] + lane < 16 * (r + 1)) buf[(size_t)row * ldS + ln[j] + lane] = 0.0;
+            } else {
+              for (int k = lane; k < 16 * (r + 1); k += 64) buf[(size_t)row * ldS + k] = 0.0;
+            }
+          }
         }
       }
+      STAMP(13);
       lds_barrier();
+      STAMP(14);
       if (r > 0) fire1(r - 1, lds + (size_t)(cur ^ 1) * B1);
       cur ^= 1;
     }
@@ -318,9 +340,9 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
       for (int r = NTMAX - 1; r >= 0; --r) {
         if (r < NTL) {   // workgroup-uniform
           double *buf = lds + (size_t)cur * B1;
-          if (isload) {
+          if (JTb == 4 || r <= LC_RSH) {   // (a column wave takes part in the staging of the short tiles only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile r have landed
-            for (int row = lidx; row < 16; row += nload) {
+            for (int row = wid; row < 16; row += 4) {
               const int c = 16 * r + row;
               if (c < P) {
                 const int len = __builtin_amdgcn_readfirstlane(s_rlen[c]);
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
           STAMP(2);
           lds_barrier();
           STAMP(3);
-          if (r > 0 && isload) issue1(r - 1, lds + (size_t)(cur ^ 1) * B1);
+          if (r > 0 && (JTb == 4 || r - 1 <= LC_RSH)) issue1(r - 1, lds + (size_t)(cur ^ 1) * B1, wid, 4);
           STAMP(4);
           if (wact) {
             d4 p = (d4){0.0, 0.0, 0.0, 0.0};
@@ -480,4 +502,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
   if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + 3);
   STAMP(11);
   STAMP_FLUSH_LEVEL(B.level);
+#ifdef FM_STAMPS
+  if (tid == 64 * JTb && JTb < 4 && (g_stamp_level < 0 || g_stamp_level == B.level)) { for (int q_ = 12; q_ < 16; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); }
+#endif
 }
