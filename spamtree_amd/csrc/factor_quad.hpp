@@ -209,15 +209,26 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   constexpr int RP = 32 / NW;   // staged rows per wave and step
   const int nit = RFL(s_nit);
   // step i of the shared chain covers chain rows [32 (nit-1-i), ...): its rows travel from global memory straight into LDS
+  // (the rows' table entries are read TOGETHER -- one LDS latency per step instead of one dependent read per row -- and the
+  // lengths stay in registers for the padding pass of the same rows one step later: rlen_nx)
+  int rlen_cur[RP], rlen_nx[RP];
+#pragma unroll
+  for (int rr = 0; rr < RP; ++rr) { rlen_cur[rr] = 0; rlen_nx[rr] = 0; }
   auto issue = [&](int i, double *buf) {
     const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
+    int lv[RP];
+    long long sv[RP];
+#pragma unroll
+    for (int rr = 0; rr < RP; ++rr) {
+      const int cc = c0 + min(wid + NW * rr, sr - 1);
+      lv[rr] = s_rlen[cc]; sv[rr] = s_rsrc[cc];
+    }
 #pragma unroll
     for (int rr = 0; rr < RP; ++rr) {
       const int row = wid + NW * rr;
-      if (row < sr) {
-        const int len = RFL(s_rlen[c0 + row]);
-        dma_row(A.panels + s_rsrc[c0 + row], buf + (size_t)row * ldS, len, lane, len > 128);
-      }
+      const int len = RFL(lv[rr]);
+      rlen_nx[rr] = len;
+      if (row < sr) dma_row(A.panels + sv[rr], buf + (size_t)row * ldS, len, lane, len > 128);
     }
   };
   // private (last) ancestors, leaf quads: sub-panel sp of every unit side by side, unit u's rows at buf + (u * stride + row) * ldS
@@ -406,14 +417,17 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     int cur = pf ? 1 : 0;
     for (int i = 0; i < nit; ++i) {
       const int c0 = 32 * (nit - 1 - i), sr = min(32, Pc - c0);
-      const int Kb = RFL(s_rlen[c0 + sr - 1]);
+      const int kb_v = s_rlen[c0 + sr - 1], kba_v = s_rlen[c0 + min(sr, 16) - 1];   // (both reads in flight together)
+      const int Kb = RFL(kb_v), KbA0 = RFL(kba_v);
       double *buf = arena + (size_t)((pf && i == 0) ? 48 : cur * 32) * ldS;
+#pragma unroll
+      for (int rr = 0; rr < RP; ++rr) rlen_cur[rr] = rlen_nx[rr];   // the lengths of the rows this wave requested for THIS step
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the current step have landed
 #pragma unroll
       for (int rr = 0; rr < RP; ++rr) {
         const int row = wid + NW * rr;
         if (row < sr) {
-          const int len = RFL(s_rlen[c0 + row]);
+          const int len = rlen_cur[rr];
           // zero from the row's own end (this also wipes the DMA's odd-length overshoot) to the step's Kb + 24
           if (len + lane < Kb + 24) buf[(size_t)row * ldS + len + lane] = 0.0;   // Kb - len <= 32 (blocks of a quad level)
         } else if (row < (sr > 16 ? 32 : 16)) {
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       STAMP(6);
       // the chain's factor is lower triangular in chain order: a row's stored length runs to the end of its ancestor's block,
       // but beyond the tile's last row index there are only (explicit) zeros -- 11 % of the V and 16 % of the T MFMAs at 25-row blocks
-      compute(buf, sr, min(Kb, c0 + 32), min(RFL(s_rlen[c0 + min(sr, 16) - 1]), c0 + 16));
+      compute(buf, sr, min(Kb, c0 + 32), min(KbA0, c0 + 16));
       STAMP(4);
       cur ^= 1;
     }
