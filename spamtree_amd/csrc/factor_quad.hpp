@@ -177,8 +177,10 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
 
   // ---- coordinates and w of the shared chain, of the private ancestors, of the units' columns
   for (int k = tid; k < Pc; k += NTQ) {
-    int t = 0;
-    while (t + 1 < Jc && k >= s_ao[t + 1]) ++t;
+    int t = 0;   // the ancestor of chain row k: independent compares (a search loop is a chain of dependent LDS reads)
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += (j < Jc && k >= s_ao[j]) ? 1 : 0;
+    for (int j = 8; j < Jc; ++j) t += (k >= s_ao[j]) ? 1 : 0;
     const long long r = s_arow[t] + (k - s_ao[t]);
     s_sx[k] = A.cx[r]; s_sy[k] = A.cy[r]; s_smv[k] = A.mv[r]; s_wpa[k] = A.w[r];
     const int len = s_ao[t + 1];
@@ -607,16 +609,22 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     if (isref) {
       double *pu = A.panels + s_bpan[u][0];
       const int ld = s_bld[u][0];
-      for (int idx = ttid; idx < Mu * Mu; idx += 128) {
-        const int i = idx / Mu, j = idx - i * Mu;
-        pu[(size_t)i * ld + Pu + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
+      {   // Ri out: thread (row group, column), no division by the block size
+        const int j = ttid & 31;
+        if (j < Mu)
+          for (int i = ttid >> 5; i < Mu; i += 4) pu[(size_t)i * ld + Pu + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
       }
-      if (ttid < Mu) {
-        const int i = ttid;
+      {   // e_i = sum_{j <= i} Ri[i][j] (w_j - hv_j): four threads per row, partial sums joined by two shuffles
+        const int i = ttid >> 2, pq = ttid & 3;
         double e = 0.0;
-        for (int j = 0; j <= i; ++j) e += Ri[i * CH_LD + j] * (s_colw[u][j] - s_hv[u][j]);
-        s_e2[u][i] = e * e;
-        s_lg[u][i] = log(Ri[i * CH_LD + i]);
+        if (i < Mu)
+          for (int j = pq; j <= i; j += 4) e += Ri[i * CH_LD + j] * (s_colw[u][j] - s_hv[u][j]);
+        e += __shfl_xor(e, 1, 64);
+        e += __shfl_xor(e, 2, 64);
+        if (i < Mu && pq == 0) {
+          s_e2[u][i] = e * e;
+          s_lg[u][i] = log(Ri[i * CH_LD + i]);
+        }
       }
     }
   }
