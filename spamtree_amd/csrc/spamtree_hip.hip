@@ -135,6 +135,16 @@ static void finish_covpar(CovPar *c) {
     }
 }
 
+// the ancestor whose rows hold chain row k (s_ao ascending, s_ao[0] = 0): independent compares -- a search loop is a chain of
+// dependent LDS reads on every block's latency path
+__device__ __forceinline__ int anc_of(const int *s_ao, int J, int k) {
+  int t = 0;
+#pragma unroll
+  for (int j = 1; j < 8; ++j) t += (j < J && k >= s_ao[j]) ? 1 : 0;
+  for (int j = 8; j < J; ++j) t += (k >= s_ao[j]) ? 1 : 0;
+  return t;
+}
+
 // workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for global loads in flight
 // (a prefetched sub-panel keeps travelling across it) nor for global stores
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -2413,7 +2423,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
   if (row) { const long long r = row0 + lane; tsq = A.tausq_inv[A.mv[r]]; yx = A.y[r] - A.xb[r]; zc = A.z[r]; }
   for (int k = lane; k < P; k += 64) {
     int t = 0;
-    while (t + 1 < J && k >= ao_of(t + 1)) ++t;
+    for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
     wv[k] = A.w[s_gd[8 + 4 * t + 1] + (k - ao_of(t))];
   }
   for (int idx = lane; idx < M * M; idx += 64) {     // Ri -> LDS (the panel's last M columns)
@@ -2488,7 +2498,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
   const int nfw = A.no_fwd ? 0 : nch;
   for (int k = lane; k < P; k += 64) {
     int t = 0;
-    while (t + 1 < J && k >= ao_of(t + 1)) ++t;
+    for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
     const int ma = am_of(t), i = k - ao_of(t);
     const long long aoff = s_gd[8 + 4 * t + 3];
     const double *avt = seg + t * 32;
@@ -2590,8 +2600,7 @@ __global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int k = lane + 64 * c;
-    int t = 0;
-    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    const int t = anc_of(s_ao, J, k);
     tk[c] = k < P ? t : -1;
     wk[c] = k < P ? A.w[s_arow[t] + (k - s_ao[t])] : 0.0;
     acc[c] = 0.0;
@@ -2646,8 +2655,7 @@ __global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
   __syncthreads();
   double *rec = A.acc + B0.acc_off;
   for (int k = tid; k < P; k += NT) {
-    int t = 0;
-    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    const int t = anc_of(s_ao, J, k);
     const int ma = s_am[t], i = k - s_ao[t];
     double a = ((red[k] + red[256 + k]) + red[512 + k]) + red[768 + k];
     for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
