@@ -533,7 +533,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       // one wave per unit, registers only (the jt = 0 waves sit on four different SIMDs, which the elimination keeps busy:
       // splitting the columns of L^{-1} over the unit's two waves would put two such waves on every SIMD)
       lds_barrier();   // R complete (both waves of the unit wrote parts of it)
-      if (jt == 0) wave_chol_eliminate<27>(R, Ri, Mu, &s_fail[u], lane);
+      if (jt == 0) wave_chol_eliminate_blocked<11>(R, Ri, Mu, &s_fail[u], lane);   // 16 + 11 blocked, DPP broadcasts + MFMA coupling (chol_blocked.hpp)
       lds_barrier();
     } else team_chol_eliminate<9>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
     STAMP(7);

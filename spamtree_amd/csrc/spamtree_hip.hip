@@ -1327,6 +1327,7 @@ __global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
 }
 
 
+#include "chol_blocked.hpp"
 #include "factor_quad.hpp"
 #include "factor_big.hpp"
 #include "factor_wide.hpp"
