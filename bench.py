@@ -44,22 +44,44 @@ def mem_available_gb():
     return 0.0
 
 
+def effective_cpus(h):
+    """CPUs this process can really use: affinity mask, bounded by the cgroup quota (or, on a gpurun box that reports none,
+    by its documented 16-CPU share per GPU)."""
+    allowed = h.get("cpus_allowed") or os.cpu_count() or 1
+    if h.get("cpu_quota"):
+        allowed = min(allowed, h["cpu_quota"])
+    elif "GRAFT_REPO_ROOT" in os.environ:
+        allowed = min(allowed, 16)
+    return max(1, allowed)
+
+
+def cpu_threads_plan():
+    """the reference path timed with OMP_NUM_THREADS = physical cores of the box (bounded by what this
+    process may use: affinity mask AND cgroup CPU quota; SPAMTREE_CPU_THREADS overrides) and with the README's
+    num_threads = 10 (/root/reference/README.md:69)."""
+    h = host_cpu()
+    allowed = effective_cpus(h)
+    full = min(h.get("physical_cores") or allowed, allowed)
+    if os.environ.get("SPAMTREE_CPU_THREADS"):
+        full = int(os.environ["SPAMTREE_CPU_THREADS"])
+    return h, max(1, full), min(10, allowed)
+
+
 def cpu_baseline(full_wl, side, seconds_budget=20.0):
     """oracle/refcpu (OpenMP restatement of the reference algorithm as written, kind="port") timed on the host cores on a
     bounded sample: full iterations (B + C + A + statistics).  When the host has the memory for the reference's caches at
     the FULL workload (about 160 GB at n = 1e6: two copies of every dense per-block matrix, profiles/r02/cpu_scaling.json)
     the sample is a few iterations of the full workload itself -- nothing is extrapolated; otherwise a smaller grid of the
     same family, scaled with the reference's own cost law (exponent 0.99 against measurements at five sizes, same file).
-    Allocation / page-touch of the caches is not timed."""
+    Allocation / page-touch of the caches is not timed.  Two thread counts (cpu_threads_plan): `value` is the faster one."""
     from oracle.refcpu import RefCpu
     from spamtree_amd.synthetic import make_workload
-    # the GPU box gives one GPU's job a 16-CPU share; the reference's README runs num_threads = 10
-    cores = int(os.environ.get("SPAMTREE_CPU_THREADS", min(os.cpu_count() or 1, 16)))
+    host, cores, readme_threads = cpu_threads_plan()
     need_gb = 165.0 * full_wl["n"] / 1.0e6 * (full_wl["q"] ** 2 if full_wl["q"] > 1 else 1)
     direct = os.environ.get("SPAMTREE_CPU_DIRECT", "1") != "0" and mem_available_gb() > need_gb + 30.0 and need_gb < 200.0
     wl = full_wl if direct else make_workload(side)
     if direct:
-        seconds_budget = 10.0
+        seconds_budget = 8.0
     rc = RefCpu(wl["y"], wl["X"], wl["coords"], wl["mv_id"], wl["res_is_ref"], wl["parents"], wl["children"],
                 wl["block_names"], wl["block_groups"], wl["indexing"], threads=cores)
     rc.set_tausq_inv(10.0)
@@ -68,36 +90,52 @@ def cpu_baseline(full_wl, side, seconds_budget=20.0):
     rc.factor(0, wl["theta"])
     if direct:
         rc.factor(1, wl["theta"])       # touch the second cache copy before the clock starts
-    its, t0 = 0, time.perf_counter()
-    while True:
-        rc.sample_w(rng.standard_normal(wl["n"]))
-        rc.loglik_w(0)
-        rc.factor(1, wl["theta"] * (1 + 0.01 * rng.standard_normal(wl["theta"].size)))
-        rc.stats()
-        its += 1
-        dt = time.perf_counter() - t0
-        if (dt > seconds_budget and its >= 3) or its >= 400:
-            break
+
+    def timed(threads, budget, min_its):
+        rc.set_threads(threads)
+        its, t0 = 0, time.perf_counter()
+        while True:
+            rc.sample_w(rng.standard_normal(wl["n"]))
+            rc.loglik_w(0)
+            rc.factor(1, wl["theta"] * (1 + 0.01 * rng.standard_normal(wl["theta"].size)))
+            rc.stats()
+            its += 1
+            dt = time.perf_counter() - t0
+            if (dt > budget and its >= min_its) or its >= 400:
+                return its, dt
+
+    runs = []
+    for threads in sorted({cores, readme_threads}, reverse=True):
+        its, dt = timed(threads, seconds_budget, 3)
+        runs.append({"threads": threads, "iterations": its, "seconds": round(dt, 2), "it_per_s_at_sample": its / dt})
     rc.close()
     ratio = 1.0 if direct else reference_cost(wl) / reference_cost(full_wl)
+    for r in runs:
+        r["value"] = r["it_per_s_at_sample"] * ratio
+    best = max(runs, key=lambda r: r["value"])
     scaling = None
     try:      # measured at several sizes on a GPU box's host by profiles/cpu_scaling.py (committed): fitted exponent vs the law
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cpu_scaling.json")))
         if f:
             scaling = json.load(open(f[-1]))
-            scaling["source"] = os.path.relpath(f[-1], ROOT)
+            scaling = {"source": os.path.relpath(f[-1], ROOT), "threads": scaling.get("threads"),
+                       "fitted_exponent_seconds_vs_cost_law": scaling.get("fitted_exponent_seconds_vs_cost_law"),
+                       "fitted_exponent_seconds_vs_n": scaling.get("fitted_exponent_seconds_vs_n")}
     except Exception:      # noqa: BLE001
         scaling = None
-    return {"value": its / dt * ratio, "unit": "Gibbs iterations/s", "cores": cores, "kind": "port", "host": host_cpu(),
+    what = (f"full iterations (B+C+A+stats) of oracle/refcpu on the FULL workload (n={wl['n']}): measured, not extrapolated"
+            if direct else
+            f"full iterations (B+C+A+stats) of oracle/refcpu on the {side}^2 grid (n={wl['n']}), scaled by the reference cost "
+            f"law (sum (P+m)^3 + 4mP^2 + ...) ratio {ratio:.4f} to n={full_wl['n']}")
+    return {"value": best["value"], "unit": "Gibbs iterations/s", "cores": best["threads"], "kind": "port", "host": host,
+            "by_threads": runs,
+            "threads_note": "SURVEY.md 8(d): min(physical cores, cpus allowed) and the reference README's num_threads = 10; "
+                            "`value` / `cores` = the faster of the two",
             "scaling_check": scaling,
-            "sample": (f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the FULL workload (n={wl['n']}) in {dt:.1f} s: "
-                       "measured, not extrapolated" if direct else
-                       f"{its} full iterations (B+C+A+stats) of oracle/refcpu on the {side}^2 grid (n={wl['n']}) in "
-                       f"{dt:.1f} s = {its / dt:.3f} it/s measured; scaled by the reference cost law "
-                       f"(sum (P+m)^3 + 4mP^2 + ...) ratio {ratio:.4f} to n={full_wl['n']}"),
+            "sample": "; ".join(f"{r['iterations']} {what} in {r['seconds']} s with {r['threads']} threads" for r in runs),
             "extrapolated": not direct,
-            "measured_it_per_s_at_sample": its / dt, "sample_n": int(wl["n"])}
+            "measured_it_per_s_at_sample": best["it_per_s_at_sample"], "sample_n": int(wl["n"])}
 
 
 def host_cpu():
@@ -115,7 +153,26 @@ def host_cpu():
         info["cpus_allowed"] = len(os.sched_getaffinity(0))
     except Exception:      # noqa: BLE001
         pass
+    info["cpu_quota"] = cgroup_cpu_quota()
     return info
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of run time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None: an affinity mask of 256 CPUs
+    says nothing when the scheduler grants 16 of them -- 128 OpenMP threads on such a share run at HALF the rate of 16."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(float(q) / float(per) + 0.5))
+        return None
+    except Exception:      # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, int(q / per + 0.5)) if q > 0 else None
+    except Exception:      # noqa: BLE001
+        return None
 
 
 def workload_name(args, wl, n_blocks, n_levels, world):
@@ -146,15 +203,34 @@ def launch_ranks(args, argv):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
+    import tempfile
+    done_flag = os.path.join(tempfile.gettempdir(), f"spamtree_bench_done_{os.getpid()}_{port}")   # rank 0 touches it after its JSON line
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, SPAMTREE_BENCH_DONE_FLAG=done_flag, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # deadline: a rank blocked inside ncclCommInitRank (or any collective) would otherwise hold the box until the driver's own
+    # limit.  Rank 0's stdout is relayed line by line; `deadline` seconds without the JSON line end exactly our child PIDs.
+    deadline = float(os.environ.get("SPAMTREE_LAUNCH_DEADLINE", "240"))
+    t_start = time.time()
     rc = 0
+    got_line = False
     try:
         alive = list(procs)
         while alive:
             time.sleep(0.2)
+            if os.path.exists(done_flag):
+                got_line = True
+            if not got_line and time.time() - t_start > deadline:
+                print(f"bench.py --gpus {args.gpus}: no JSON line after {deadline:.0f} s (a rank is probably blocked in "
+                      "ncclCommInitRank or a collective); terminating the ranks started here", file=sys.stderr, flush=True)
+                rc = 124
+                for pr in alive:
+                    pr.terminate()
+                t_kill = time.time() + 10.0
+                while time.time() < t_kill and any(pr.poll() is None for pr in alive):
+                    time.sleep(0.2)
+                break
             for pr in list(alive):
                 code = pr.poll()
                 if code is None:
@@ -168,18 +244,57 @@ def launch_ranks(args, argv):
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
+        try:
+            os.unlink(done_flag)
+        except OSError:
+            pass
     raise SystemExit(rc)
+
+
+def mark_done():
+    """Tell the launcher (launch_ranks) that rank 0 is about to print its JSON line: the deadline no longer applies."""
+    flag = os.environ.get("SPAMTREE_BENCH_DONE_FLAG")
+    if flag:
+        try:
+            open(flag, "w").close()
+        except OSError:
+            pass
+
+
+class Watchdog:
+    """Per-rank deadline for launches through torch.distributed.run (which bypass launch_ranks): a rank that has not
+    finished its timed region `seconds` after start-up -- blocked in ncclCommInitRank, a collective or a barrier because
+    another rank died or never arrived -- says so and exits 124, so the launcher tears the job down in minutes instead of
+    holding the node until the driver's own limit."""
+
+    def __init__(self, seconds, rank):
+        import threading
+        self.t = threading.Timer(seconds, self._fire, args=(seconds, rank))
+        self.t.daemon = True
+        self.t.start()
+
+    @staticmethod
+    def _fire(seconds, rank):
+        print(f"bench.py rank {rank}: no result after {seconds:.0f} s (blocked in ncclCommInitRank / a collective?); exiting 124",
+              file=sys.stderr, flush=True)
+        os._exit(124)
+
+    def cancel(self):
+        self.t.cancel()
 
 
 def launch_check(rank, world):
     """CPU rehearsal of the launcher's env plumbing (tests/test_bench_launcher.py): gloo group from the env the launcher set."""
     import torch
     import torch.distributed as dist
+    if os.environ.get("SPAMTREE_LAUNCH_CHECK_HANG") == str(rank):      # rehearsal of a rank that never reaches the collective
+        time.sleep(3600)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
     dist.barrier()
     if rank == 0:
+        mark_done()
         print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
                           "local_rank_env": os.environ.get("LOCAL_RANK"), "master": os.environ.get("MASTER_ADDR")}), flush=True)
     dist.destroy_process_group()
@@ -233,6 +348,8 @@ def main():
     ap.add_argument("--cell-size", type=int, default=25, help="knots per cell (config #5: 9)")
     ap.add_argument("--missing", type=str, default="", help="per-outcome drop probabilities, e.g. 0.1,0.3,0.5 (config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stationary-windows", type=int, default=12,
+                    help="at most this many untimed 50-iteration windows after the timed region until one accepts >= 20 %% (0 = skip)")
     ap.add_argument("--cpu-side", type=int, default=316, help="grid side of the bounded CPU-baseline sample")
     ap.add_argument("--external", action="store_true", help="force the torch.distributed + Python-driver fallback path")
     ap.add_argument("--launch-check", action="store_true", help="CPU rehearsal of the rank launcher (gloo, no GPU work)")
@@ -254,6 +371,7 @@ def main():
         return
     import torch
     dist = None
+    dog = Watchdog(float(os.environ.get("SPAMTREE_LAUNCH_DEADLINE", "240")), rank) if world > 1 else None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -362,13 +480,14 @@ def main():
     it_s = args.steps / dt
     # HBM bytes per k_factor launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # separate passes, FETCH_SIZE doubled as the gfx950 guide prescribes); only valid for the workload it was taken on
-    traffic, pmc_file = None, None
+    traffic, pmc_file, pmc_commit = None, None, None
     try:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, PMC_GLOB)), key=lambda f: (os.path.basename(os.path.dirname(f)), os.path.basename(f)))
-        if cands and world == 1 and args.side == 1000 and args.q == 1 and args.cell_size == 25 and not args.missing:
-            pmc_file = os.path.relpath(cands[-1], ROOT)
-            pmc = json.load(open(cands[-1]))
+        # the counter summary is named EXPLICITLY (profiles/pmc_source.json: file + the commit it was measured at), not
+        # picked by sort order
+        src = json.load(open(os.path.join(ROOT, "profiles", "pmc_source.json")))
+        if world == 1 and args.side == 1000 and args.q == 1 and args.cell_size == 25 and not args.missing:
+            pmc_file, pmc_commit = src["file"], src.get("commit")
+            pmc = json.load(open(os.path.join(ROOT, pmc_file)))
             # per launch of the timed bracket: the k_factor_quad launches when the top levels run ahead, else all of phase A
             traffic = pmc["summary"]["k_factor_quad" if g_top > 0 else "phase_A"]["hbm_bytes_per_launch"]
     except Exception:      # noqa: BLE001
@@ -379,6 +498,7 @@ def main():
     if traffic is not None and avg_launch_ms > 0:
         g = traffic / (avg_launch_ms * 1e-3) / 1e9
         hbm_measured = {"bytes_per_launch": traffic, "GBps": g, "frac": g / HBM_PEAK_GBS, "source": pmc_file,
+                        "source_commit": pmc_commit,
                         "note": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, same command"}
     fp64_achieved = alg["flops_A"] * share / (avg_launch_ms * n_bracket * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     all_ms = float(np.sum(lvl_ms))
@@ -386,6 +506,53 @@ def main():
                   "GBps": round(float(np.sum(lvl_bytes)) * share / (all_ms * 1e-3) / 1e9, 1) if all_ms > 0 else 0.0,
                   "frac": round(float(np.sum(lvl_bytes)) * share / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if all_ms > 0 else 0.0,
                   "note": "every level of phase A run back to back on one stream (the per-launch pass), algorithmic bytes"}
+    # box-measured peaks: a stream copy and the FP64 matrix / vector pipes, ~0.15 s, outside the timed region
+    peak_measured = None
+    try:
+        import ctypes as C
+        from spamtree_amd import _lib
+        pk = np.zeros(3)
+        if _lib.load().st_probe_peaks(local_rank, 1 << 30, 5, pk.ctypes.data_as(C.POINTER(C.c_double))) == 0:
+            peak_measured = {"stream_copy_GBps": round(float(pk[0]), 1), "fp64_mfma_TFLOPs": round(float(pk[1]), 2),
+                             "fp64_fma_TFLOPs": round(float(pk[2]), 2),
+                             "frac_of_stream_copy": round(achieved / pk[0], 4) if pk[0] > 0 else None,
+                             "fp64_frac_of_mfma": round(fp64_achieved / pk[1], 4) if pk[1] > 0 else None,
+                             "note": "this box, this run: float4-wide copy of 1 GiB (read + written bytes), v_mfma_f64_16x16x4_f64 "
+                                     "and v_fma_f64 loops at 2 waves per SIMD (csrc/probe.hip); `peak` stays the vendor figure"}
+    except Exception as exc:      # noqa: BLE001
+        peak_measured = {"error": repr(exc)}
+
+    # stationary throughput: the timed window above starts at the data-generating theta with a 0.01 I proposal, where the
+    # adaptation has not reached its 0.234 target yet, so it under-samples the sweeps that follow an ACCEPTED theta (the
+    # records' Gram parts are rebuilt: dearer).  Untimed extra windows until one has accepted >= 20 % of its proposals
+    # (bounded), then THAT window's rate; plus the cached / rebuild sweep times for an acceptance-weighted estimate.
+    stationary = None
+    if world == 1 and args.stationary_windows > 0:
+        try:
+            win = max(20, min(50, args.steps))
+            st0 = chain.state()
+            acc0, it0 = st0["accept_ratio"] * st0["iteration"], st0["iteration"]
+            hist = []
+            for wdx in range(args.stationary_windows):
+                fence()
+                tw = time.perf_counter()
+                chain.step(win)
+                fence()
+                tw = time.perf_counter() - tw
+                st1 = chain.state()
+                acc1, it1 = st1["accept_ratio"] * st1["iteration"], st1["iteration"]
+                ar = (acc1 - acc0) / max(1, it1 - it0)
+                hist.append({"iterations": int(it1 - it0), "accept": round(float(ar), 3), "it_per_s": round(win / tw, 2)})
+                acc0, it0 = acc1, it1
+                if ar >= 0.2:
+                    break
+            stationary = {"value": hist[-1]["it_per_s"], "unit": "Gibbs iterations/s", "window_accept_ratio": hist[-1]["accept"],
+                          "reached_0.2": bool(hist[-1]["accept"] >= 0.2), "windows": hist,
+                          "note": f"windows of {win} iterations after the timed region, not part of `value`; the last one is reported"}
+        except Exception as exc:      # noqa: BLE001
+            stationary = {"error": repr(exc)}
+
+    info1 = model.shard_info() if world > 1 else None
     out = {
         "metric": "Gibbs iterations/sec + achieved HBM GB/s, n=1e6 grid, 1/2/4/8 MI355X",
         "value": it_s, "unit": "Gibbs iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -396,7 +563,22 @@ def main():
                    "mh_accept_ratio": float(chain.state()["accept_ratio"]),
                    "algorithmic_bytes_per_iter": alg["total"], "algorithmic_flops_per_iter":
                        alg["flops_A"] + alg["flops_B"] + alg["flops_C"], "setup_s": round(t_setup, 2)},
-        "roofline": {"bound": "hbm", "kernel": "k_factor (phase A: covariance build + chain solve + Cholesky)"
+        "stationary": stationary,
+        "multi_gpu": None if world == 1 else {
+            "n_gpus": world, "rccl_ranks": int(info1["world"]), "cut_level": int(info1["cut_level"]),
+            "owned_rows_rank0": int(info1["owned_rows"]), "native_rccl": bool(native),
+            "collective_ms_per_iter": round(prof_all.get("comm", (0.0, 0))[0] / n_extra, 4),
+            "collective_launches_per_iter": prof_all.get("comm", (0.0, 0))[1] / n_extra,
+            "note": "rank 0's view; collective time = HIP events around the library's RCCL calls on its stream in the untimed "
+                    "bracketed pass (includes waiting for the slowest rank)"},
+        "roofline": {"bound": "mfma",
+                     "bound_note": "what limits the kernel by the counters is the FP64 matrix / vector pipe (ONE pipe per SIMD: "
+                                   "fp64_pipe below) and latency, not HBM (hbm_measured ~0.1 of peak).  achieved / peak / frac / unit "
+                                   "stay the CONTRACT figure of north_star and SURVEY.md 8(d): algorithmic bytes per launch over the "
+                                   "launch time against the 8 TB/s HBM roofline",
+                     "contract_bound": "hbm",
+                     "peak_measured": peak_measured,
+                     "kernel": "k_factor (phase A: covariance build + chain solve + Cholesky)"
                      + (f"; levels {g_top}-{n_levels - 1} (levels 0-{g_top - 1}, 0.4 % of the bytes, run ahead of time on a second "
                         "stream under the sweep and are not in the timed bracket)" if g_top > 0 else ""),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -426,7 +608,10 @@ def main():
                                       "steps; by_level_ms and the other families: an untimed pass of "
                                       f"{n_extra} steps with every launch bracketed (event traffic costs 4-6 % of an iteration)"},
     }
+    if dog is not None:
+        dog.cancel()
     if rank == 0:
+        mark_done()
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(wl, args.cpu_side)

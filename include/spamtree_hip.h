@@ -147,11 +147,16 @@ int st_get_comps(st_handle h, int slot, double *logdetCi_comps, double *loglik_w
 /* ---- measurement: algorithmic bytes of one iteration (SURVEY.md section 8d operand-streaming model)
  * out[0..4] = phase A, B, C, messages, S1+S2;  flops[0..2] = A, B, C (may be NULL). */
 int st_algorithmic_bytes(st_handle h, double *out5, double *flops3);
+/* box-measured peaks for the roofline report (csrc/probe.hip; no handle needed): out3[0] = stream-copy GB/s (read + written
+ * bytes, `bytes` per buffer, best of `reps`), out3[1] = FP64 MFMA TFLOP/s (v_mfma_f64_16x16x4_f64), out3[2] = FP64 FMA TFLOP/s
+ * (v_fma_f64).  About 0.15 s. */
+int st_probe_peaks(int device, int64_t bytes, int reps, double *out3);
 /* per-kernel-family device time from HIP events recorded on the launch stream around every launch (enable=1), or around
  * the phase-A launches only (enable=2: the roofline measurement at a third of the event traffic; ~60 event records per
  * iteration cost 4-6 % of the iteration at n = 1e6).  Events are harvested lazily: no host synchronisation is added.
- * families: 0 factor(A) 1 sample(B) 2 loglik(C) 3 reduce 4 stats/xb 5 rng 6 predict */
-#define ST_N_KERNEL_FAMILIES 7
+ * families: 0 factor(A) 1 sample(B) 2 loglik(C) 3 reduce 4 stats/xb 5 rng 6 predict 7 comm (the library's RCCL collectives
+ * on the launch stream: device time between the events, i.e. including the wait for the slowest rank) */
+#define ST_N_KERNEL_FAMILIES 8
 int st_profile_enable(st_handle h, int enable);
 int st_profile_get(st_handle h, double *ms_total, int64_t *launches); /* ST_N_KERNEL_FAMILIES each; resets */
 /* phase-A launches by tree level since the last call: mean ms per launch, algorithmic bytes per launch; resets */

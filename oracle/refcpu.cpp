@@ -533,6 +533,16 @@ void *refcpu_create(long long n_all, int q, int p, long long n_blocks, int n_gro
   return M;
 }
 void refcpu_destroy(void *h) { delete (RefModel *)h; }
+
+// thread count of the per-level `#pragma omp parallel for` loops from now on (the reference's num_threads argument,
+// /root/reference/src/spamtree_fit.cpp:56-58): bench.py times one model at several counts without re-allocating its caches
+void refcpu_set_threads(int num_threads) {
+#ifdef _OPENMP
+  if (num_threads > 0) omp_set_num_threads(num_threads);
+#else
+  (void)num_threads;
+#endif
+}
 int refcpu_factor(void *h, int slot, const double *theta, int ntheta, double *loglik) {
   RefModel *M = (RefModel *)h;
   Data &d = M->dat[M->slot_map[slot]];

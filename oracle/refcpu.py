@@ -23,6 +23,7 @@ def load():
         _lib.refcpu_create.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_longlong, C.c_int, _dp, _dp, _dp, _ip, _ip, _ip,
                                        _ip, _ip, _ip, _ip, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int]
         _lib.refcpu_destroy.argtypes = [C.c_void_p]
+        _lib.refcpu_set_threads.argtypes = [C.c_int]
         _lib.refcpu_factor.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
         _lib.refcpu_sample_w.argtypes = [C.c_void_p, _dp]
         _lib.refcpu_loglik_w.restype = C.c_double
@@ -80,6 +81,9 @@ class RefCpu:
             self.close()
         except Exception:
             pass
+
+    def set_threads(self, threads):
+        self.lib.refcpu_set_threads(int(threads))
 
     def factor(self, slot, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)

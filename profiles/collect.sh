@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash profiles/collect.sh TAG'): bench line, rocprofv3 kernel-trace statistics and the
 # two HBM counter passes (separate --pmc runs, kernel-trace only) of the same bench command; raw output under
-# gpurun_out/ (merged back by gpurun); profiles/summarize.py, run afterwards in the repo, writes profiles/<round>/<TAG>_* (ROUND env, default r02).
+# gpurun_out/ (merged back by gpurun); profiles/summarize.py, run afterwards in the repo, writes profiles/<round>/<TAG>_* (ROUND env, default r03).
 TAG=${1:-c_quad}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out

@@ -1,5 +1,5 @@
 """Condenses the raw rocprofv3 output of profiles/collect.sh (gpurun_out/<tag>_*) into the committed summaries
-profiles/<round>/<tag>_bench.json (ROUND env, default r02), <tag>_kernel_stats.csv and <tag>_pmc_hbm.json.
+profiles/<round>/<tag>_bench.json (ROUND env, default r03), <tag>_kernel_stats.csv and <tag>_pmc_hbm.json.
 
 HBM bytes per kernel family = FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md: 128-byte requests are
 tallied at 64 bytes) + WRITE_SIZE, both reported by rocprofv3 in KB, from separate counter passes."""
@@ -14,7 +14,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "c_quad"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out")
-dst = os.path.join(root, "profiles", os.environ.get("ROUND", "r02"))
+dst = os.path.join(root, "profiles", os.environ.get("ROUND", "r03"))
 os.makedirs(dst, exist_ok=True)
 
 
@@ -61,6 +61,13 @@ if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
 out["summary"] = summ
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1))
+if summ:
+    # bench.py reads the counter summary named HERE (file + the commit whose working tree was measured), not the last one by name
+    import subprocess
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "spamtree_amd", "include"], capture_output=True, text=True).stdout.strip())
+    json.dump({"file": os.path.relpath(os.path.join(dst, f"{tag}_pmc_hbm.json"), root), "commit": head, "uncommitted_source_changes": dirty,
+               "workload": "config #3 (bench.py defaults), one GPU"}, open(os.path.join(root, "profiles", "pmc_source.json"), "w"), indent=1)
 
 # ---- SQ counter pass (collect.sh, own --pmc run): per kernel INSTANTIATION (the quad kernel's template arguments tell the
 # levels apart), means per launch; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs)

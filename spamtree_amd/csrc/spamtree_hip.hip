@@ -4499,7 +4499,10 @@ static int exchange_comps_and_finish(st_handle h, int slot, double *loglik) {
   int64_t len = 0;
   int rc = st_mg_pack_comps(h, slot, &ptr, &len);
   if (rc) return rc;
-  NCHK(h, ncclAllReduce(ptr, ptr, (size_t)len, ncclDouble, ncclSum, h->comm, h->stream));
+  {
+    ProfScope ps(h, 7);
+    NCHK(h, ncclAllReduce(ptr, ptr, (size_t)len, ncclDouble, ncclSum, h->comm, h->stream));
+  }
   return st_mg_finish(h, loglik);
 }
 
@@ -4560,7 +4563,10 @@ extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, u
     // log-density components travel in ONE grouped RCCL call, followed by ONE host synchronisation.
     int rc = st_sample_w_local(h, z, seed, iter);
     if (rc) return rc;
-    if (h->top_len > 0) NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
+    if (h->top_len > 0) {
+      ProfScope ps(h, 7);
+      NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
+    }
     rc = st_sample_w_top(h);
     if (rc) return rc;
     void *pw = nullptr, *pr = nullptr, *pc = nullptr;
@@ -4571,10 +4577,13 @@ extern "C" int st_sample_w_loglik(st_handle h, const double *z, uint64_t seed, u
     if (rc) return rc;
     rc = st_mg_pack_comps(h, slot, &pc, &lc);
     if (rc) return rc;
-    NCHK(h, ncclGroupStart());
-    NCHK(h, ncclAllGather(pw, pr, (size_t)lw, ncclDouble, h->comm, h->stream));
-    NCHK(h, ncclAllReduce(pc, pc, (size_t)lc, ncclDouble, ncclSum, h->comm, h->stream));
-    NCHK(h, ncclGroupEnd());
+    {
+      ProfScope ps(h, 7);
+      NCHK(h, ncclGroupStart());
+      NCHK(h, ncclAllGather(pw, pr, (size_t)lw, ncclDouble, h->comm, h->stream));
+      NCHK(h, ncclAllReduce(pc, pc, (size_t)lc, ncclDouble, ncclSum, h->comm, h->stream));
+      NCHK(h, ncclGroupEnd());
+    }
     rc = gather_w_scatter(h);
     if (rc) return rc;
     invalidate_stats(h);
@@ -4837,14 +4846,20 @@ extern "C" int st_sample_w(st_handle h, const double *z, uint64_t seed, uint32_t
     if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_sample_w_local / st_mg_top_region / st_sample_w_top / st_mg_pack_w / st_mg_unpack_w"; return ST_ERR_USAGE; }
     int rc = st_sample_w_local(h, z, seed, iter);
     if (rc) return rc;
-    if (h->top_len > 0) NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
+    if (h->top_len > 0) {
+      ProfScope ps(h, 7);
+      NCHK(h, ncclAllReduce(h->d_acc.p + h->top_off, h->d_acc.p + h->top_off, (size_t)h->top_len, ncclDouble, ncclSum, h->comm, h->stream));
+    }
     rc = st_sample_w_top(h);
     if (rc) return rc;
     void *snd = nullptr, *rcv = nullptr;
     int64_t cnt = 0;
     rc = st_mg_gather_w_pack(h, &snd, &rcv, &cnt);
     if (rc) return rc;
-    NCHK(h, ncclAllGather(snd, rcv, (size_t)cnt, ncclDouble, h->comm, h->stream));
+    {
+      ProfScope ps(h, 7);
+      NCHK(h, ncclAllGather(snd, rcv, (size_t)cnt, ncclDouble, h->comm, h->stream));
+    }
     return st_mg_gather_w_unpack(h);
   }
   int rc = st_sample_w_local(h, z, seed, iter);

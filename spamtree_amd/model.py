@@ -255,10 +255,10 @@ class SpamTreeMV:
         self._check(self.lib.st_profile_enable(self.h, 2 if enable == 2 else int(bool(enable))))
 
     def profile_get(self):
-        ms = np.zeros(7)
-        n = np.zeros(7, dtype=np.int64)
+        ms = np.zeros(8)
+        n = np.zeros(8, dtype=np.int64)
         self._check(self.lib.st_profile_get(self.h, _dp(ms), _ip(n)))
-        names = ["factor", "sample", "loglik", "reduce", "stats", "rng", "predict"]
+        names = ["factor", "sample", "loglik", "reduce", "stats", "rng", "predict", "comm"]
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
 
     def profile_levels(self):
