@@ -96,6 +96,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ int s_nit;   // steps of 32 chain rows over the shared chain
   __shared__ double s_sx[PMAX], s_sy[PMAX], s_wpa[PMAX];
   __shared__ int s_smv[PMAX];
+  __shared__ double s_exp2[64];         // 2^(j/64): cov_exp_tab
   __shared__ int s_rlen[PMAX];          // chain row c: its length (entries up to and including its own ancestor's rows) ...
   __shared__ long long s_rsrc[PMAX];    // ... and where it starts in the panel arena
 
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     gdl[e] = A.gdesc[(size_t)(Q.g0 + uu) * gds + i];
   }
   for (int k = tid; k < ldS; k += NTQ) zrow[k] = 0.0;
+  if (tid < 64) s_exp2[tid] = EXP2_64[tid];
   __syncthreads();
   if (tid < NU) {
     int M = 0, P = 0, blk0 = 0, nblk = 0, isref = 0, J = 0, pm = 0;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
               if (k >= Pc) { ax = s_px[u][(k - Pc) & 31]; ay = s_py[u][(k - Pc) & 31]; }
             }
             const double dx = ax - mx, dy = ay - my;
-            const double v = s2 * cov_exp(nphi * cov_sqrt(fma(dx, dx, dy * dy)));
+            const double v = s2 * cov_exp_tab(nphi * cov_sqrt(fma(dx, dx, dy * dy)), s_exp2);
             kb[i * 64] = (cok && k < Pu) ? v : 0.0;
           }
         } else {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
               if constexpr (!ISREF) {
                 if (k >= Pc) { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
               }
-              v = cov_entry(cp, ax, ay, av, mx, my, mvj);
+              v = cov_entry_tab(cp, s_exp2, ax, ay, av, mx, my, mvj);
             }
             kb[i * 64] = v;
           }

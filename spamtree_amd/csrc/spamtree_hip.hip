@@ -86,6 +86,44 @@ __device__ __forceinline__ double cov_exp(double x) {
   return __builtin_ldexp(p, (int)t);   // |t| < 2^31 after the clamp above, or +huge -> saturating conversion -> inf
 }
 
+// exp(x) with a 64-entry table of 2^(j/64) (in LDS: EXP2_64 copied by the kernel), for the covariance pass of k_factor_quad,
+// which runs at the FP64 pipe's issue rate (44 FP64 instructions per entry, 4 cycles each, stamps of round 3): the reduced
+// argument is |r| <= ln2/128, so a degree-5 polynomial is exact to 3.5e-17 and the whole exponential costs 16 FP64
+// instructions + one LDS read instead of 24.  x = t ln2/64 + r, t = 64 k + j: exp(x) = 2^k 2^(j/64) e^r.  Relative error
+// < 3e-16 (the table entries are correctly rounded); over- / underflow as cov_exp.
+__device__ const double EXP2_64[64] = {
+  0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+  0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+  0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+  0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+  0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+  0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+  0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+  0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+  0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+  0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+  0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+  0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+  0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+  0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+  0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+  0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+__device__ __forceinline__ double cov_exp_tab(double x, const double *tab) {
+  x = fmax(x, -1500.0);
+  const double t = __builtin_rint(x * 9.233248261689366e+01);          // 64 / ln 2
+  double r = fma(t, -1.08304246932675596327e-02, x);                   // ln2 / 64: the 32-bit head of cov_exp's split, scaled
+  r = fma(t, -2.98158582698529328128e-12, r);
+  const int ti = (int)t;
+  const double T = tab[ti & 63];
+  const double r2 = r * r;
+  const double a0 = 1.0 + r;
+  const double a1 = fma(1.6666666666666666e-01, r, 0.5);
+  const double a2 = fma(8.3333333333333332e-03, r, 4.1666666666666664e-02);
+  const double p = fma(fma(a2, r2, a1), r2, a0);
+  return __builtin_ldexp(p * T, ti >> 6);
+}
+
 // sqrt(a) for squared distances (a >= 0): v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections (the
 // library's scheme without its range scaling).  a is clamped to 1e-300 from below, so coincident points give 1e-150
 // instead of 0 (exp(-phi * 1e-150) == 1 exactly); squared distances above ~1e300 are outside the contract.
@@ -111,6 +149,17 @@ __device__ __forceinline__ double cov_entry(const CovPar &c, double xi, double y
   double r = c.amp[ij] * cov_exp(-c.rate[ij] * h);
   const double a2 = c.amp2[ij];
   if (a2 != 0.0) r += a2 * cov_exp(-c.phi[vi] * h);
+  return r;
+}
+
+__device__ __forceinline__ double cov_entry_tab(const CovPar &c, const double *tab, double xi, double yi, int vi, double xj, double yj, int vj) {
+  const double dx = xi - xj, dy = yi - yj;
+  const double h = cov_sqrt(dx * dx + dy * dy);
+  if (c.q == 1) return c.ai1[0] * cov_exp_tab(-c.tmv[0] * h, tab);
+  const int ij = vi * c.q + vj;
+  double r = c.amp[ij] * cov_exp_tab(-c.rate[ij] * h, tab);
+  const double a2 = c.amp2[ij];
+  if (a2 != 0.0) r += a2 * cov_exp_tab(-c.phi[vi] * h, tab);
   return r;
 }
 

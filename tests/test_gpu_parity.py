@@ -42,6 +42,9 @@ CASES = [
     # q = 3 with cell_size = 9 (config #5's shape): 27-row blocks -> the MFMA kernels evaluate the Apanasovich-Genton form
     dict(side=18, q=3, missing=0.25, cell_size=9),
     dict(side=20, q=2, missing=0.0, cell_size=16),
+    # config #5 AS SPECIFIED (BASELINE.json configs[4]; NA census spamtree_model.cpp:303-313, quirk Q3 :1375): outcomes dropped
+    # with probabilities 10 / 30 / 50 %, q = 3, cell_size = 9, the NA rows in their own prediction level
+    dict(side=24, q=3, missing=(0.1, 0.3, 0.5), cell_size=9),
     # unusual trees: 3 x 2 branching, small cells, a finite depth with a nearest-neighbour leftover level
     dict(side=30, q=1, missing=0.1, cell_size=9, K=(3, 2)),
     dict(side=30, q=1, missing=0.0, tree_depth=2),
@@ -64,6 +67,9 @@ def test_factor_sample_loglik_predict_match_oracle(case, generic):
     beta = np.array([0.3, -0.2, 0.1])
     om = oracle_model(pb, w=w0, beta=beta, tausq=0.2)
     hm = hip_model(pb, w=w0, beta=beta, tausq=0.2, force_generic=generic)
+    if np.ndim(case["missing"]) > 0:      # the imbalanced pattern really is imbalanced, and there is something to predict
+        n_obs = np.array([np.sum(np.isfinite(pb["y"][pb["mv_id"] == j + 1])) for j in range(pb["q"])])
+        assert n_obs[0] > n_obs[1] > n_obs[2] and np.any(np.asarray(om.block_ct_obs) == 0)
     # ---- phase A on both slots
     assert om.get_loglik_comps_w(om.param_data)
     assert hm.get_loglik_comps_w(0)

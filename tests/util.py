@@ -67,7 +67,10 @@ def make_problem(side=25, q=1, seed=0, missing=0.0, coords=None, mv_id=None, p=3
         kx, ky, ph = rng.uniform(1, 6), rng.uniform(1, 6), rng.uniform(0, 6.28)
         f += rng.normal() * np.sin(kx * coords[:, 0] + ky * coords[:, 1] + ph + 0.7 * mv_id)
     y = X @ beta + f + np.sqrt(0.1) * rng.standard_normal(n)
-    if missing > 0:
+    if np.ndim(missing) > 0:      # per-outcome drop probabilities (config #5: 0.1, 0.3, 0.5 -- imbalanced)
+        y = y.copy()
+        y[rng.uniform(size=n) < np.asarray(missing, dtype=np.float64)[np.asarray(mv_id) - 1]] = np.nan
+    elif missing > 0:
         y = y.copy()
         y[rng.uniform(size=n) < missing] = np.nan
     limited_tree = bool(tree_kw.get("limited_tree", False))
