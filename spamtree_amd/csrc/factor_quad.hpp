@@ -646,9 +646,12 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     if (ttid < s_unblk[u]) {
       const int bi = ttid;
       double wc = 0.0, ldt = 0.0;
-      int cnt = 0;
-      for (int j = 0; j < Mu; ++j)
-        if (s_colblk[u][j] == bi) { wc += s_e2[u][j]; ldt += s_lg[u][j]; ++cnt; }
+      // the block's columns are consecutive (device rows s_brow[bi] .. s_brow[bi + 1] - 1 of the unit): walk those only, in
+      // the same ascending order as a scan of all Mu columns would (3.5 % of a leaf quad's life went into that scan)
+      const int j0 = (int)(s_brow[u][bi] - s_urow0[u]);
+      const int j1 = bi + 1 < s_unblk[u] ? (int)(s_brow[u][bi + 1] - s_urow0[u]) : Mu;
+      const int cnt = j1 - j0;
+      for (int j = j0; j < j1; ++j) { wc += s_e2[u][j]; ldt += s_lg[u][j]; }
       A.logdet_c[s_ublk0[u] + bi] = ldt;
       A.loglik_c[s_ublk0[u] + bi] = (double)cnt * HL2PI - 0.5 * wc;
     }
