@@ -49,10 +49,11 @@ struct QuadArgs {
 
 // Row stride (doubles) of the staged chain rows, a function of the instantiation only, so that every LDS operand address
 // of the main loop is ONE per-lane base register + an immediate offset: >= the longest chain (4 NKX) + 24 zero-filled
-// columns, >= 178 (the epilogue's per-unit overlay: Ri, R, T hand-over slots), and 2 x odd (conflict-free A-operand reads).
+// columns, >= 186 (the epilogue's per-unit overlay of 16 rows: Ri [0, 1056), then one 192-double hand-over slot per T tile --
+// ceil(4 NKX / 16) of them -- over R and the elimination scratch), and 2 x odd (conflict-free A-operand reads).
 constexpr int QUAD_LEAF_KH = 5;   // leaf levels: K-steps per pass of the covariance scratch (8 waves x 5 x 64 doubles behind the arena)
 __host__ __device__ constexpr int quad_lds_stride(int nkx) {
-  int s = 4 * nkx + 24 > 178 ? 4 * nkx + 24 : 178;
+  int s = 4 * nkx + 24 > 186 ? 4 * nkx + 24 : 186;
   while ((s & 1) || ((s >> 1) & 1) == 0) ++s;
   return s;
 }
@@ -539,9 +540,99 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       lds_barrier();
     } else team_chol_eliminate<9>(R, Ri, Mu, Mmax, pub, &s_fail[u], ttid);
     STAMP(7);
+    double *xT = Ri + 32 * CH_LD;
+    if constexpr (WCH) {
+      // ---- N = -Ri T, blocks of <= 27 rows.  The jt = 1 wave owns columns 16 .. 26 only (accumulator registers r = 0 .. 2):
+      // it hands ALL its T tiles to its partner in ONE exchange (192 doubles per chain tile, over R and the elimination scratch:
+      // quad_lds_stride leaves room for every tile) and the jt = 0 wave forms every tile of N -- rows 0-15 from its own T alone
+      // (Ri is lower triangular), rows 16+ from both.  A SIMD hosts one jt = 0 and one jt = 1 wave of different units, so the
+      // matrix work per SIMD is what the alternating scheme had (121 against 132 MFMAs), without its second round, its
+      // hand-over in both directions and two of its three workgroup barriers; the jt = 1 wave meanwhile writes Ri and forms the
+      // residuals e = Ri (w - hv).
+      static_assert(NKT * 192 <= 16 * quad_lds_stride(NKX) - 32 * CH_LD, "T hand-over slots must fit the unit's LDS region");
+      if (jt == 1) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (kt * 16 < Pu) {
+            double *sl = xT + kt * 192 + lane;
+            sl[0] = tacc[kt][0]; sl[64] = tacc[kt][1]; sl[128] = tacc[kt][2];
+          }
+        }
+      }
+      double nri0[2][4], nri1[3];   // -Ri as A operands: [row tile][K-step] over columns 0-15; row tile 1 over columns 16-27
+      if (jt == 0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int i_a = it * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 4 * r + l4;
+            nri0[it][r] = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int i_a = 16 + l15, j = 16 + 4 * r + l4;
+          nri1[r] = (i_a < Mu && j <= i_a) ? -Ri[i_a * CH_LD + j] : 0.0;
+        }
+      }
+      lds_barrier();
+      double *pu = A.panels + s_bpan[u][0];
+      const int ld = s_bld[u][0];
+      if (jt == 0) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          if (kt * 16 < Pu) {
+            const double *sl = xT + kt * 192 + lane;
+            const double t10 = sl[0], t11 = sl[64], t12 = sl[128];
+            const int k = kt * 16 + l15;
+            d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri0[0][r], tacc[kt][r], c, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int io = l4 + 4 * r;
+              if (io < Mu && k < Pu) pu[(size_t)io * ld + k] = c[r];
+            }
+            if (two) {
+              c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri0[1][r], tacc[kt][r], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri1[0], t10, c, 0, 0, 0);
+              if (20 < Mu) c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri1[1], t11, c, 0, 0, 0);
+              if (24 < Mu) c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri1[2], t12, c, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int io = 16 + l4 + 4 * r;
+                if (io < Mu && k < Pu) pu[(size_t)io * ld + k] = c[r];
+              }
+            }
+          }
+        }
+      } else {
+        {   // Ri out: lane (row parity, column)
+          const int j = lane & 31;
+          if (j < Mu)
+            for (int i = lane >> 5; i < Mu; i += 2) pu[(size_t)i * ld + Pu + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // e_i = sum_{j <= i} Ri[i][j] (w_j - hv_j): four lanes per row, the same partial sums as the 128-thread form
+          const int i = half * 16 + (lane >> 2), pq = lane & 3;
+          double e = 0.0;
+          if (i < Mu)
+            for (int j = pq; j <= i; j += 4) e += Ri[i * CH_LD + j] * (s_colw[u][j] - s_hv[u][j]);
+          e += __shfl_xor(e, 1, 64);
+          e += __shfl_xor(e, 2, 64);
+          if (i < Mu && pq == 0) {
+            s_e2[u][i] = e * e;
+            s_lg[u][i] = log(Ri[i * CH_LD + i]);
+          }
+        }
+      }
+      STAMP(8);
+    } else {
     // ---- N = -Ri T.  Chain tiles alternate between the unit's two waves; the non-owner hands its T tile over through
     // LDS (slots overlay R and the elimination scratch), so the owner holds T for all of the unit's columns.
-    double *xT = Ri + 32 * CH_LD;
     constexpr int NR = (NKT + 6) / 7;
     // -Ri as A operands, the same for every chain tile: [row tile it][K-step r] (column tile 0), [r] (row tile 1, column tile 1)
     double nri0[2][4], nri1[4];
@@ -629,6 +720,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
         }
       }
     }
+    }   // !WCH
   }
   STAMP(12);
   lds_barrier();
