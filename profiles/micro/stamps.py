@@ -1,6 +1,6 @@
 """Diagnostic (not part of the product): where k_factor_quad's time goes, per tree level.
 Build the stamped library first:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DFM_STAMPS -I include
-  -I spamtree_amd/csrc -o profiles/micro/libspamtree_hip_stamps.so spamtree_amd/csrc/*.cpp spamtree_amd/csrc/*.hip -lrccl
+  -I spamtree_amd/csrc -o profiles/micro/libspamtree_hip_stamps.so spamtree_amd/csrc/*.cpp spamtree_amd/csrc/*.hip -lrccl   (per-family accessors: st_debug_stamps = k_factor_quad, _mfma, _wide, _sample, _generic)
 Run on the GPU box:  python profiles/micro/stamps.py [side]"""
 import ctypes as C
 import os

@@ -24,17 +24,17 @@ hm = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocki
                 wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"], wl["indexing"],
                 np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"], 10.0, device=0)
 lib = hm.lib
-lib.st_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-lib.st_debug_stamp_level.argtypes = [C.c_int]
+lib.st_debug_stamps_wide.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+lib.st_debug_stamp_level_wide.argtypes = [C.c_int]
 hm.get_loglik_comps_w(0)
 nlev = len(np.unique(np.asarray(wl["block_groups"])))
 lev = nlev - 1
-lib.st_debug_stamp_level(lev)
+lib.st_debug_stamp_level_wide(lev)
 buf = (C.c_ulonglong * 16)()
-lib.st_debug_stamps(buf, 1)
+lib.st_debug_stamps_wide(buf, 1)
 for _ in range(2):
     hm.get_loglik_comps_w(1)
-lib.st_debug_stamps(buf, 0)
+lib.st_debug_stamps_wide(buf, 0)
 v = np.array(list(buf), dtype=np.float64)
 tot = v.sum()
 print(f"level {lev}: total ticks {tot:.3e}")

@@ -22,19 +22,19 @@ hm = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocki
                 wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"], wl["indexing"],
                 np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"], 10.0, device=0)
 lib = hm.lib
-lib.st_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-lib.st_debug_stamp_level.argtypes = [C.c_int]
+lib.st_debug_stamps_sample.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+lib.st_debug_stamp_level_sample.argtypes = [C.c_int]
 hm.get_loglik_comps_w(0)
 rng = np.random.default_rng(0)
 hm.deal_with_w(rng.standard_normal(wl["n"]))       # builds the cached Gram parts
 nlev = len(np.unique(np.asarray(wl["block_groups"])))
 for lev in (2, nlev - 3, nlev - 2, nlev - 1):
-    lib.st_debug_stamp_level(lev)
+    lib.st_debug_stamp_level_sample(lev)
     buf = (C.c_ulonglong * 16)()
-    lib.st_debug_stamps(buf, 1)
+    lib.st_debug_stamps_sample(buf, 1)
     for _ in range(2):
         hm.deal_with_w(rng.standard_normal(wl["n"]))
-    lib.st_debug_stamps(buf, 0)
+    lib.st_debug_stamps_sample(buf, 0)
     v = np.array(list(buf), dtype=np.float64)
     tot = v.sum()
     if tot == 0:

@@ -16,6 +16,7 @@
 //   Rm: LDS, row stride CH_LD, lower triangle valid; destroyed.   Bm: LDS, receives L^{-1} (lower triangle only; what lies
 //   above the diagonal is not written).  All 64 lanes of the wave must call; no barrier inside (single wave: LDS program order).
 #pragma once
+#ifdef ST_DEFS_FACTOR_QUAD
 
 template <int J>
 __device__ __forceinline__ void fmac_bcast(double &d, const double src, const double f) {
@@ -145,3 +146,4 @@ __device__ __forceinline__ void wave_chol_eliminate_blocked(double *Rm, double *
   }
   if (bad && lane == 0) *fail = 1;
 }
+#endif   // ST_DEFS_FACTOR_QUAD

@@ -19,6 +19,7 @@
 // BM_JT column tiles x BM_KTW chain tiles per wave in registers; BM_KTP <= 8 BM_KTW chain tiles per pass: <5, 3, 24> for
 // blocks up to 80 columns (two passes beyond 384 rows), <4, 5, 34> / <3, 5, 34> for blocks up to 64 / 48 columns (the
 // leaves of the default multivariate tree: one pass).
+#ifdef ST_DEFS_FACTOR_WIDE
 template <int BM_JT, int BM_KTW, int BM_KTP>
 __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPar cp) {
   extern __shared__ double lds[];
@@ -371,5 +372,9 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
   }
   STAMP_FLUSH_LEVEL(st_level);
 }
-
-
+template __global__ void k_factor_bigmfma<3, 5, 34>(FactorArgs, CovPar);
+template __global__ void k_factor_bigmfma<4, 5, 34>(FactorArgs, CovPar);
+template __global__ void k_factor_bigmfma<5, 3, 24>(FactorArgs, CovPar);
+#else   // host side: prototypes only
+template <int BM_JT, int BM_KTW, int BM_KTP> __global__ void k_factor_bigmfma(FactorArgs A, CovPar cp);
+#endif

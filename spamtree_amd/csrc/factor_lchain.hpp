@@ -38,6 +38,28 @@ __host__ __device__ constexpr size_t lc_dyn_doubles(int nkx) {   // dynamic LDS:
 // cov_entry with the per-pair constants in LDS (tab: rate | amp | amp2 | phi, QMAX^2 / QMAX entries each).  MV: branch-free
 // multivariate form (the second exponential is always evaluated and enters with amplitude amp2 = 0 where the reference has
 // no such term: the same value) so that several independent evaluations can be interleaved; !MV: cexpcov.
+struct LcSlab {
+  long long row0;   // first device row (column) of the slab
+  long long pan0;   // panel arena offset of that row's panel row (rows of the group follow each other with stride ld)
+  int blk0;         // a block of the group: chain, level
+  int ncol, ld, pad;
+};
+
+struct LcArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const LcSlab *slabs;
+  int nslab;
+  const double *cx, *cy;
+  const int *mv;
+  const double *w_in;
+  double *panels;
+  double *rowtmp;   // per device row: e_j^2 | log r_j (2 x n_rows), summed per block by k_lchain_scalars in row order
+  long long n_rows;
+  int *errflag;
+};
+
+#ifdef ST_DEFS_FACTOR_WIDE
 template <bool MV>
 __device__ __forceinline__ double lc_cov(const double *tab, int q, double s2, double nphi, double xi, double yi, int vi, double xj, double yj, int vj) {
   const double dx = xi - xj, dy = yi - yj;
@@ -53,25 +75,6 @@ __device__ __forceinline__ double lc_cov(const double *tab, int q, double s2, do
 // A workgroup's columns: a SLAB of a sibling group -- up to 64 consecutive columns of the concatenated rows of consecutive
 // blocks with one parent (= one chain; device order keeps siblings, their rows and their panels contiguous).  Tiles of 16
 // columns may straddle blocks: four 36-column leaves are nine full tiles instead of twelve (16 + 16 + 4 each).
-struct LcSlab {
-  long long row0;   // first device row (column) of the slab
-  long long pan0;   // panel arena offset of that row's panel row (rows of the group follow each other with stride ld)
-  int blk0;         // a block of the group: chain, level
-  int ncol, ld, pad;
-};
-struct LcArgs {
-  const Blk *blks;
-  const int *anc_idx;
-  const LcSlab *slabs;
-  int nslab;
-  const double *cx, *cy;
-  const int *mv;
-  const double *w_in;
-  double *panels;
-  double *rowtmp;   // per device row: e_j^2 | log r_j (2 x n_rows), summed per block by k_lchain_scalars in row order
-  long long n_rows;
-  int *errflag;
-};
 
 // per-block scalars from the per-row values (fixed order: independent of the slabs' composition and of the launch geometry)
 __global__ void k_lchain_scalars(const Blk *blks, const int *list, int nlist, const double *rowtmp, long long n_rows, double *logdet_c, double *loglik_c) {
@@ -506,3 +509,9 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
   if (tid == 64 * JTb && JTb < 4 && (g_stamp_level < 0 || g_stamp_level == B.level)) { for (int q_ = 12; q_ < 16; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); }
 #endif
 }
+template __global__ void k_factor_lchain<96>(LcArgs, CovPar);
+template __global__ void k_factor_lchain<136>(LcArgs, CovPar);
+#else   // host side: prototypes only
+__global__ void k_lchain_scalars(const Blk *blks, const int *list, int nlist, const double *rowtmp, long long n_rows, double *logdet_c, double *loglik_c);
+template <int NKX> __global__ void k_factor_lchain(LcArgs A, CovPar cp);
+#endif

@@ -58,12 +58,11 @@ __host__ __device__ constexpr int quad_lds_stride(int nkx) {
   return s;
 }
 
+#ifdef ST_DEFS_FACTOR_QUAD
 // One row of Kb doubles, global -> LDS, by LDS-DMA (16 bytes per lane, 1 KiB per wave-instruction, no registers): lane l
 // moves doubles 2l, 2l+1 of each 128-double piece.  The source needs 8-byte alignment only.  When Kb is odd the last
 // active lane also drops the row's successor into column Kb: the caller zero-fills [Kb, Kb+24) after the data has landed.
 // `two`: issue the second piece (wave-uniform; callers that count instructions pass Kb > 128).
-typedef __attribute__((address_space(3))) void q_lds_void;
-typedef __attribute__((address_space(1))) const void q_glb_void;
 __device__ __forceinline__ void dma_row(const double *src, double *dst, int Kb, int lane, bool two) {
   if (2 * lane < Kb) __builtin_amdgcn_global_load_lds((q_glb_void *)(src + 2 * lane), (q_lds_void *)dst, 16, 0, 0);
   if (two) {
@@ -752,3 +751,18 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   STAMP(13);
   STAMP_FLUSH_LEVEL(s_level);
 }
+template __global__ void k_factor_quad<4, 32, 8, true, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 32, 8, true, false>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 32, 8, false, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 38, 10, true, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 38, 10, true, false>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 38, 10, false, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 44, 11, true, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 44, 11, true, false>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 44, 11, false, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 50, 13, true, true>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 50, 13, true, false>(QuadArgs, CovPar);
+template __global__ void k_factor_quad<4, 50, 13, false, true>(QuadArgs, CovPar);
+#else   // host side: prototypes only
+template <int NU, int NKX, int NKT, bool ISREF, bool WCH> __global__ void k_factor_quad(QuadArgs A, CovPar cp);
+#endif

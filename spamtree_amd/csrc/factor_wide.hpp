@@ -44,6 +44,7 @@ struct WideArgs {
   int maxP, maxN, maxM, maxMa, ldS;
 };
 
+#ifdef ST_DEFS_FACTOR_WIDE
 template <int WJT>
 __global__ __launch_bounds__(WG_NT, 2) void k_factor_wide(WideArgs A, CovPar cp) {
   extern __shared__ double lds[];
@@ -353,3 +354,7 @@ __global__ __launch_bounds__(WG_NT, 2) void k_factor_wide(WideArgs A, CovPar cp)
     }
   }
 }
+template __global__ void k_factor_wide<WG_JT>(WideArgs, CovPar);
+#else   // host side: prototypes only
+template <int WJT> __global__ void k_factor_wide(WideArgs A, CovPar cp);
+#endif

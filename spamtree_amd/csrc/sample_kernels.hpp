@@ -1,0 +1,1337 @@
+// Phase B kernels (block-Gibbs sweep of w) and the Gram-part builders.
+#pragma once
+#include "st_device.hpp"
+
+struct SampleArgs {
+  const Blk *blks;
+  const int *anc_idx;
+  const int *dch_idx;
+  const int *list;
+  int nlist;
+  const double *panels;  // param_data slot
+  double *w;
+  const double *y, *xb, *z;
+  const int *mv;
+  const unsigned char *obs;
+  double *acc;           // message arena
+  int *errflag;
+  double *scratch;       // BIG: staged S matrix
+  long long scratch_stride;
+  int maxP, maxM, maxLd;
+  int do_gram;
+  int no_fwd;   // limited_tree: a block's record goes to its single parent only, nothing is forwarded from its children
+  int lds_sq;   // BIG: 2 = the posterior precision lives in LDS after the vectors (maxM x (maxM | 1) + maxM doubles) and ONE wave
+                // factorises and solves there (wave_chol_solve_lds); 0 = scratch arena + workgroup-wide loops
+  double *s0;              // theta-only part Ri' Ri of every reference block's posterior precision, cached like the records'
+  const long long *s0off;  // Gram parts: per block, offset into s0 (row stride m) or -1
+  double tausq_inv[QMAX];
+};
+
+struct GramBigArgs {
+  const Blk *blks;
+  const int *anc_idx, *dch_idx;
+  const int *list;
+  int nlist;
+  const double *panels;
+  double *acc;
+  double *s0;
+  const long long *s0off;
+  int no_fwd;
+};
+
+struct SampleFastArgs {
+  const Blk *blks;
+  const int *anc_idx, *dch_idx;
+  const Grp *grps;
+  int ngrp;
+  const double *panels;
+  double *w;
+  const double *y, *xb, *z;
+  const int *mv;
+  double *acc;
+  int *errflag;
+  const long long *gdesc;   // group descriptors of this launch's first group onwards
+  int gd_stride;
+  int ldN, Mr4, Mrows, maxP, av_dbl;   // Mrows: staged panel rows (the level's largest group)   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
+  int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
+  int no_fwd;    // limited_tree: nothing is forwarded from the children's records
+  double tausq_inv[QMAX];
+};
+
+#ifdef ST_DEFS_SAMPLE
+
+// w = L^{-T} (L^{-1} b + z), S = L L' (spamtree_model.cpp:1054, 1086), for blocks too wide for one wave's registers (75-row
+// blocks of the default multivariate tree), by ONE wave with S in LDS and NO workgroup barrier: the scratch-arena path pays
+// three __syncthreads() per pivot for the factorisation and four per row for the two substitutions (about a millisecond per
+// 75-row block, most of phase B at config #4).  Lane i owns rows i and i + 64 (m <= 128); right-looking elimination, the
+// scaled pivot column goes through `lcol` (m doubles of LDS) so that a batch of eight trailing columns costs four wide
+// uniform reads; the right-hand side rides along (forward substitution for free); the backward substitution walks L by rows.
+//   S: m x m (m <= 80), row stride ms (odd: conflict-free column walks; >= m + 7), lower triangle valid, destroyed.
+//   lcol: m + 8 doubles.  bv (LDS): in b, out w.
+//   zg: the block's normals (global).  All 64 lanes of the wave must call; nobody else may touch S, lcol, bv meanwhile.
+__device__ __forceinline__ void wave_chol_solve_lds(double *S, int ms, double *lcol, double *bv, const double *zg, int m, int *fail, int lane) {
+  // rows 0 .. 63: lane i owns row i.  Rows 64 .. m - 1 (at most 16: m <= 80): lane (g, r) = (lane >> 4, lane & 15) works on
+  // row 64 + r, and the four lane groups take DIFFERENT column batches of one trip (eleven rows on a row-per-lane mapping
+  // would pay a whole wave-instruction stream for 17 % of its lanes)
+  const int i0 = lane, i1 = 64 + (lane & 15), g1 = lane >> 4;
+  const bool r0 = i0 < m, r1 = i1 < m;
+  const bool two = m > 64;   // wave-uniform
+  double c0 = r0 ? bv[i0] : 0.0, c1 = r1 ? bv[i1] : 0.0;   // c1, dr1, t1: replicated in the four lanes of a row
+  double dr0 = 1.0, dr1 = 1.0;   // 1 / L_kk of this lane's rows
+  bool bad = false;
+  for (int j = lane; j < m + 8; j += 64) lcol[j] = 0.0;
+  for (int k = 0; k < m; ++k) {
+    const double d = S[(size_t)k * ms + k];
+    bad = bad || !(d > 0.0);
+    double rp = __builtin_amdgcn_rsq(d);            // 1 / sqrt(d): hardware seed + two Newton steps (relative error < 1e-16)
+    rp = rp * fma(-0.5 * d * rp, rp, 1.5);
+    rp = rp * fma(-0.5 * d * rp, rp, 1.5);
+    const bool u0 = r0 && i0 > k, u1 = r1 && i1 > k;
+    const double l0 = u0 ? S[(size_t)i0 * ms + k] * rp : 0.0;
+    const double l1 = u1 ? S[(size_t)i1 * ms + k] * rp : 0.0;
+    const double ck = readlane_f64(k < 64 ? c0 : c1, k & 63);   // (row 64 + r: lane r of group 0)
+    const double yk = ck * rp;
+    c0 = (i0 == k) ? yk : fma(-l0, yk, c0);
+    c1 = (i1 == k) ? yk : fma(-l1, yk, c1);
+    dr0 = (i0 == k) ? rp : dr0;
+    dr1 = (i1 == k) ? rp : dr1;
+    if (u0) { S[(size_t)i0 * ms + k] = l0; lcol[i0] = l0; }
+    if (u1 && g1 == 0) { S[(size_t)i1 * ms + k] = l1; lcol[i1] = l1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: its LDS operations complete in order
+    // trailing columns in batches of eight, WITHOUT per-element predicates: rows at or above the pivot carry l = 0 (no-ops),
+    // entries above the diagonal and the columns past m - 1 that a batch reaches (row stride ms >= m + 7, lcol: m + 8) are
+    // scribbled on and never read
+    if (r0) {
+      double *row = S + (size_t)i0 * ms;
+      for (int j0 = k + 1; j0 < m; j0 += 8) {
+        // (requesting the next batch before this one's stores would save about a tenth of the solve, but its 16 extra VGPRs
+        // take the kernel past 128 and the leaf levels, which share it, from four waves per SIMD to three: measured, dropped)
+        double lj[8], a0[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lj[q] = lcol[j0 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a0[q] = row[j0 + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) row[j0 + q] = fma(-l0, lj[q], a0[q]);
+      }
+    }
+    if (two) {   // wave-uniform
+      if (r1) {
+        double *row = S + (size_t)i1 * ms;
+        for (int j0 = k + 1 + 8 * g1; j0 < m; j0 += 32) {
+          double lj[8], a1[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) lj[q] = lcol[j0 + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a1[q] = row[j0 + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) row[j0 + q] = fma(-l1, lj[q], a1[q]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (bad && lane == 0) *fail = 1;
+  // S now holds L below the diagonal (column k scaled by 1 / L_kk); c = L^{-1} b.  Backward: w_k = t_k / L_kk, t_j -= L_kj w_k
+  double t0 = r0 ? c0 + zg[i0] : 0.0, t1 = r1 ? c1 + zg[i1] : 0.0;
+  for (int k = m - 1; k >= 0; --k) {
+    const double wk = readlane_f64(k < 64 ? t0 : t1, k & 63) * readlane_f64(k < 64 ? dr0 : dr1, k & 63);
+    t0 = (i0 == k) ? wk : ((r0 && i0 < k) ? fma(-S[(size_t)k * ms + i0], wk, t0) : t0);
+    if (two) t1 = (i1 == k) ? wk : ((r1 && i1 < k) ? fma(-S[(size_t)k * ms + i1], wk, t1) : t1);
+  }
+  if (r0) bv[i0] = t0;
+  if (r1 && g1 == 0) bv[i1] = t1;
+}
+
+
+// NOREF: the level holds non-reference blocks only (the host knows): the reference branch -- whose blocked factorisation takes
+// 224 VGPRs -- is compiled out, so that leaf levels keep four waves per SIMD
+template <bool BIG, bool NOREF = false>
+__global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ int s_fail;
+  __shared__ long long s_choff[16];    // record offsets of the first direct children (one read per block instead of one per entry)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int maxP = A.maxP, maxM = A.maxM;
+  double *wv = lds;                    // maxP + maxM
+  double *tv = wv + (maxP + maxM);     // maxM   N w_pa
+  double *ev = tv + maxM;              // maxM   Ri w_u + N w_pa
+  double *bv = ev + maxM;              // maxM   rhs / solution
+  double *av = bv + maxM;              // maxM   per-ancestor temp
+  double *seg = av + maxM;             // MAXJ * maxM: seg[t][r] = sum_j N[r][oa_t + j] w_a[j], later ev[r] - seg[t][r]
+  double *Np = seg + (size_t)MAXJ * maxM;   // !BIG: maxM * maxLd panel copy
+  double *S = BIG ? (A.lds_sq ? Np : A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
+
+  STAMP_DECL
+  int st_lev = 0;
+  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
+    const int b = A.list[li];
+    const Blk B = A.blks[b];
+    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+    st_lev = B.level;
+    __syncthreads();
+    STAMP(7);
+    if (tid < J) {
+      const int a = A.anc_idx[B.anc_ptr + tid];
+      s_am[tid] = A.blks[a].m;
+      s_arow[tid] = A.blks[a].row0;
+    }
+    if (tid == 0) s_fail = 0;
+    if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      long long ao = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+      s_ao[J] = o; s_aoff[J] = ao;
+    }
+    __syncthreads();
+    for (int t = 0; t < J; ++t) {
+      const long long r0 = s_arow[t];
+      for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[r0 + i];
+    }
+    const double *pg = A.panels + B.panel_off;
+    const double *N;  // m x ld, row-major: [ -Ri*H | Ri or r ]
+    if (BIG) {
+      N = pg;
+    } else {
+      for (int idx = tid; idx < m * ld; idx += NT) Np[idx] = pg[idx];
+      N = Np;
+    }
+    __syncthreads();
+    for (int i0 = 4 * wid; i0 < m; i0 += 4 * (NT / 64)) {   // four rows per trip: their loads travel together
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < P; k += 64) {
+        const double wk = wv[k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (i0 + q < m) a4[q] += N[(size_t)(i0 + q) * ld + k] * wk;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double r = wave_sum(a4[q]);
+        if (lane == 0 && i0 + q < m) tv[i0 + q] = r;
+      }
+    }
+    __syncthreads();
+
+    STAMP(0);
+    if (!NOREF && B.isref) {
+      const double *Ri = N + P;  // Ri[i][j] = N[i*ld + P + j]
+      // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
+      const int ms = (BIG && A.lds_sq) ? ((m + 7) | 1) : m;   // row stride of S
+      const long long so = (BIG && A.s0off) ? A.s0off[b] : -1;
+#pragma unroll 4
+      for (int idx = tid; idx < m * m; idx += NT) {
+        const int i = idx / m, j = idx - i * m;
+        if (j <= i) {
+          double acc = 0.0;
+          if (so >= 0 && !A.do_gram) acc = A.s0[so + idx];   // Ri' Ri is a function of theta only
+          else {
+            for (int k = i; k < m; ++k) acc += Ri[(size_t)k * ld + i] * Ri[(size_t)k * ld + j];
+            if (so >= 0) A.s0[so + idx] = acc;
+          }
+          for (int c = 0; c < B.ndch; ++c) {
+            const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
+            acc += A.acc[co + B.acc_len + idx];
+          }
+          if (i == j) acc += A.tausq_inv[A.mv[B.row0 + i]];
+          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = acc; else S[(size_t)i * ms + j] = acc;
+        } else {
+          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = 0.0; else S[(size_t)i * ms + j] = 0.0;
+        }
+      }
+      // Smu_tot = A_u' w_pa + sum_children Smu_children + tausq_inv*(y - XB)   (:1062-1077)
+      for (int i = tid; i < m; i += NT) {
+        double acc = 0.0;
+        // - Ri' (N w_pa), walking Ri by ROWS (thread i reads entry i of row k: coalesced; same summation order as the column walk)
+        for (int k0 = 0; k0 < m; k0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) x[q] = (k0 + q < m && k0 + q >= i) ? Ri[(size_t)(k0 + q) * ld + i] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (k0 + q < m && k0 + q >= i) acc -= x[q] * tv[k0 + q];
+        }
+        for (int c = 0; c < B.ndch; ++c) {
+          const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
+          acc += A.acc[co + B.acc_len + m * m + i];
+        }
+        const long long r = B.row0 + i;
+        acc += A.tausq_inv[A.mv[r]] * (A.y[r] - A.xb[r]);
+        bv[i] = acc;
+      }
+      if (BIG && A.lds_sq) {
+        // w_u = L^{-T} (L^{-1} Smu + z) by wave 0 alone, S in LDS (no workgroup barrier inside)
+        __syncthreads();
+        STAMP(1);
+        // (Np, not S: S is `lds_sq ? LDS : scratch arena`, a generic pointer -- the compiler would emit FLAT loads and stores,
+        // six times slower than ds_read / ds_write here)
+        if (m > 32) block_chol_solve_mfma(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail);   // (workgroup-uniform)
+        else if (wid == 0) wave_chol_solve_lds(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail, lane);
+      } else {
+      chol_lower_inplace(S, m, &s_fail);
+      // w_u = L^{-T} (L^{-1} Smu + z)   (= Sigi_chol' (Sigi_chol Smu + z), :1086)
+      for (int k = 0; k < m; ++k) {
+        __syncthreads();
+        const double xk = bv[k] / S[k * m + k];
+        __syncthreads();
+        if (tid == 0) bv[k] = xk;
+        for (int i = k + 1 + tid; i < m; i += NT) bv[i] -= S[i * m + k] * xk;
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) bv[i] += A.z[B.row0 + i];
+      for (int k = m - 1; k >= 0; --k) {
+        __syncthreads();
+        const double xk = bv[k] / S[k * m + k];
+        __syncthreads();
+        if (tid == 0) bv[k] = xk;
+        for (int i = tid; i < k; i += NT) bv[i] -= S[k * m + i] * xk;
+      }
+      }
+      __syncthreads();
+      STAMP(2);
+      for (int i = tid; i < m; i += NT) {
+        wv[P + i] = bv[i];
+        A.w[B.row0 + i] = bv[i];
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) {
+        double acc = tv[i];
+        for (int j = 0; j <= i; ++j) acc += Ri[(size_t)i * ld + j] * wv[P + j];
+        ev[i] = acc;
+      }
+    } else {
+      // non-reference rows (:1091-1155)
+      for (int i = tid; i < m; i += NT) {
+        const long long r = B.row0 + i;
+        const double ri = N[(size_t)i * ld + P];
+        const double tsq = A.tausq_inv[A.mv[r]];
+        const double sig = ri * ri + tsq;
+        if (!(sig > 0.0)) s_fail = 1;
+        const double mu = -ri * tv[i] + tsq * (A.y[r] - A.xb[r]);
+        const double c = 1.0 / sqrt(sig);
+        const double wi = c * c * mu + c * A.z[r];
+        wv[P + i] = wi;
+        A.w[r] = wi;
+        ev[i] = ri * wi + tv[i];
+      }
+    }
+    __syncthreads();
+    STAMP(3);
+    // messages to every ancestor (:1158-1207), summed with the direct children's accumulated messages
+    if (!A.do_gram) {
+      // Gram parts cached (Q4): only the vectors.  All ancestors at once, as in k_sample_lean: thread (row r, ancestor t)
+      // sums its segment N[r][oa_t ..] w_a, then thread k (a chain column) accumulates -sum_r N[r][k] (ev[r] - seg_t(k)[r])
+      for (int idx = tid; idx < m * J; idx += NT) {
+        const int r = idx / J, t = idx - r * J;
+        const int ma = s_am[t], oa = s_ao[t];
+        const double *row = N + (size_t)r * ld + oa;
+        const double *wa = wv + oa;
+        double a = 0.0;
+        for (int j0 = 0; j0 < ma; j0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+        }
+        seg[t * maxM + r] = ev[r] - a;
+      }
+      __syncthreads();
+      STAMP(4);
+      double *rec = A.acc + B.acc_off;
+      for (int k = tid; k < P; k += NT) {
+        int t = 0;
+        while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+        const int ma = s_am[t], i = k - s_ao[t];
+        const double *avt = seg + t * maxM;
+        double a = 0.0;
+        for (int r0 = 0; r0 < m; r0 += 8) {
+          double x[8];
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < m) ? N[(size_t)(r0 + rr) * ld + k] : 0.0;
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) a -= x[rr] * ((r0 + rr < m) ? avt[r0 + rr] : 0.0);
+        }
+        for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
+          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
+          a += A.acc[C.acc_off + s_aoff[t] + ma * ma + i];
+        }
+        rec[s_aoff[t] + ma * ma + i] = a;
+      }
+      STAMP(5);
+      if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
+      continue;
+    }
+    long long off = 0;
+    for (int t = 0; t < J; ++t) {
+      const int ma = s_am[t], oa = s_ao[t];
+      for (int r = tid; r < m; r += NT) {
+        double acc = ev[r];
+        for (int j = 0; j < ma; ++j) acc -= N[(size_t)r * ld + oa + j] * wv[oa + j];
+        av[r] = acc;
+      }
+      __syncthreads();
+      double *out = A.acc + B.acc_off + off;
+      for (int idx = A.do_gram ? tid : ma * ma + tid; idx < ma * ma + ma; idx += NT) {
+        double acc = 0.0;
+        if (idx < ma * ma) {
+          const int i = idx / ma, j = idx - i * ma;
+          for (int r = 0; r < m; ++r) acc += N[(size_t)r * ld + oa + i] * N[(size_t)r * ld + oa + j];
+        } else {
+          const int i = idx - ma * ma;
+          for (int r = 0; r < m; ++r) acc -= N[(size_t)r * ld + oa + i] * av[r];
+        }
+        for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
+          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
+          acc += A.acc[C.acc_off + off + idx];
+        }
+        out[idx] = acc;
+      }
+      off += (long long)ma * ma + ma;
+      __syncthreads();
+    }
+    if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
+  }
+  STAMP_FLUSH_LEVEL(st_lev);
+}
+
+
+// The theta-only parts of the generic path's message records -- Sigma_a = N_a' N_a per ancestor a, plus the direct children's
+// (spamtree_model.cpp:1162, 1190-1192) -- and of the posterior precision (Ri' Ri) on the FP64 matrix cores,
+// ahead of a sweep that then takes k_sample's cached branch.  k_sample's own do_gram branch builds them with one thread per
+// entry and a strided global walk per product: 35 ms for the leaf level of config #4 (16 384 blocks x 7 ancestors x 75 x 75
+// entries x 36 rows) against 2.2 ms for the sweep itself.  One workgroup per block; a task = one 16 x 16 tile (it >= jt) of
+// one ancestor's Gram matrix, tasks dealt over the four waves; both MFMA operands are rows of the block's panel, straight
+// from global memory / L2 (16 consecutive doubles per row: whole 128-byte segments).  Fixed summation order.
+
+__global__ __launch_bounds__(NT) void k_gram_big(GramBigArgs A) {
+  __shared__ int s_am[MAXJ + 1], s_ao[MAXJ + 1], s_t0[MAXJ + 2];
+  __shared__ long long s_aoff[MAXJ + 1];
+  __shared__ long long s_choff[16];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = A.list[blockIdx.x];
+  const Blk B = A.blks[b];
+  const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+  const long long so = (B.isref && A.s0off) ? A.s0off[b] : -1;
+  if (tid < J) s_am[tid] = A.blks[A.anc_idx[B.anc_ptr + tid]].m;
+  if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
+  __syncthreads();
+  if (tid == 0) {
+    int o = 0, tasks = 0;
+    long long ao = 0;
+    for (int t = 0; t < J; ++t) {
+      const int nt = (s_am[t] + 15) >> 4;
+      s_ao[t] = o; s_aoff[t] = ao; s_t0[t] = tasks;
+      o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; tasks += nt * (nt + 1) / 2;
+    }
+    s_t0[J] = tasks;
+    if (so >= 0) { s_am[J] = m; s_ao[J] = P; s_aoff[J] = 0; const int nt = (m + 15) >> 4; tasks += nt * (nt + 1) / 2; }
+    s_t0[J + 1] = tasks;
+  }
+  __syncthreads();
+  const double *N = A.panels + B.panel_off;
+  double *rec = A.acc + B.acc_off;
+  const int ntask = s_t0[J + 1], ns = (m + 3) >> 2;
+  const int nch = A.no_fwd ? 0 : B.ndch;
+  for (int e = wid; e < ntask; e += NT / 64) {
+    int t = 0;
+    while (e >= s_t0[t + 1]) ++t;
+    int it = 0, pe = e - s_t0[t];
+    while ((it + 1) * (it + 2) / 2 <= pe) ++it;
+    const int jt = pe - it * (it + 1) / 2;
+    const int ma = s_am[t], oa = s_ao[t];
+    const int ci = 16 * it + l15, cj = 16 * jt + l15;
+    const double *ap = N + (size_t)l4 * ld + oa + min(ci, ma - 1), *bp = N + (size_t)l4 * ld + oa + min(cj, ma - 1);
+    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+    int st = 0;
+    for (; st + 4 <= ns; st += 4) {   // eight operand loads in flight per lane
+      double a4[4], b4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool rok = 4 * (st + q) + l4 < m;
+        a4[q] = (rok && ci < ma) ? ap[(size_t)4 * (st + q) * ld] : 0.0;
+        b4[q] = (rok && cj < ma) ? bp[(size_t)4 * (st + q) * ld] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
+    }
+    for (; st < ns; ++st) {
+      const bool rok = 4 * st + l4 < m;
+      const double a1 = (rok && ci < ma) ? ap[(size_t)4 * st * ld] : 0.0, b1 = (rok && cj < ma) ? bp[(size_t)4 * st * ld] : 0.0;
+      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+    }
+    // C layout: entry (i = 16 it + 4 q + l4, j = 16 jt + l15); the mirrored entry of an off-diagonal tile gets the same value
+    const bool isS0 = t == J;
+    double *out = isS0 ? A.s0 + so : rec + s_aoff[t];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 16 * it + 4 * q + l4, j = cj;
+      if (i < ma && j < ma) {
+        double v = c[q];
+        if (!isS0) {
+          for (int ch = 0; ch < nch; ++ch) {
+            const long long co = ch < 16 ? s_choff[ch] : A.blks[A.dch_idx[B.dch_ptr + ch]].acc_off;
+            v += A.acc[co + s_aoff[t] + (size_t)i * ma + j];
+          }
+        }
+        out[(size_t)i * ma + j] = v;
+        if (it != jt) out[(size_t)j * ma + i] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, fast path: one workgroup per column group (same groups as k_factor_mfma).  A sibling group of
+// non-reference blocks is treated as ONE block with a diagonal Ri: the Gram of the stacked panel rows is the sum
+// of the siblings' messages, so the group writes one message record (at its first block) instead of one per block.
+// Gram matrices N_a' N_a run on the FP64 matrix cores; the m x m posterior Cholesky and both triangular solves
+// run in the registers of wave 0.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32];
+  __shared__ int s_bld[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];               // message records of the direct children
+  __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int ldN = A.ldN, Mr4 = A.Mr4;
+  double *Np = lds;                              // maxM x ldN (no pad rows: the Gram tiles mask rows >= M)
+  double *wv = Np + (size_t)A.Mrows * ldN + 32;  // maxP + 32 : ancestors' w, then the group's new w
+  double *tv = wv + A.maxP + 32, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32;
+  double *av = zc + 32;                          // MAXJ x 32
+  int *colblk = (int *)(av + A.av_dbl);          // 32 ints
+  double *S = av + A.av_dbl + 16;                // reference levels only: maxM x CH_LD
+  double *Li = S;                                // chol(S)^{-1} replaces S (the elimination reads S once, writes at the end)
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  STAMP_DECL
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
+  if (tid < 32) {
+    const int j = tid;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      tsq[j] = A.tausq_inv[A.mv[r]]; yx[j] = A.y[r] - A.xb[r]; zc[j] = A.z[r];
+      int bi = 0;
+      while (bi + 1 < G.nblk && r >= s_gd[8 + 4 * J + 3 * (bi + 1) + 1]) ++bi;
+      colblk[j] = bi;
+    } else {
+      tsq[j] = 0.0; yx[j] = 0.0; zc[j] = 0.0; colblk[j] = 0;
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+  }
+  STAMP(0);
+  // panel rows -> LDS (row j of the group = one panel row of its block); pad rows / columns zero.
+  // Each wave takes rows wid, wid+4, ...; all loads of four rows are issued before the first LDS store.
+  const int rowlen = P + (refgrp ? M : 1);
+  for (int jb = 0; jb < Mr4; jb += 16) {
+    double tmp[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = jb + wid + 4 * rr;
+      const int jc = min(j, M - 1);
+      const int bi = colblk[jc];
+      const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = lane + 64 * c;
+        tmp[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = jb + wid + 4 * rr;
+      if (j < M) {
+        double *dst = Np + (size_t)j * ldN;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int k = lane + 64 * c;
+          if (k < ldN) dst[k] = tmp[rr][c];
+        }
+        for (int k = 256 + lane; k < ldN; k += 64) dst[k] = 0.0;
+      }
+    }
+  }
+  for (int j = wid; j < M; j += NT / 64) {          // rows longer than 256 columns (P + M > 256)
+    const int bi = colblk[j];
+    const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + j - s_brow[bi]) * s_bld[bi];
+    for (int k = 256 + lane; k < rowlen; k += 64) Np[(size_t)j * ldN + k] = src[k];
+  }
+  __syncthreads();
+  STAMP(1);
+  for (int j = wid; j < M; j += NT / 64) {
+    double a = 0.0;
+    const double *row = Np + (size_t)j * ldN;
+    for (int k = lane; k < P; k += 64) a += row[k] * wv[k];
+    a = wave_sum(a);
+    if (lane == 0) tv[j] = a;
+  }
+  __syncthreads();
+  STAMP(2);
+  if (refgrp) {
+    const double *Ri = Np + P;   // Ri[i][j] = Np[i*ldN + P + j]
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      double a = 0.0;
+      if (j <= i) {
+        double ch[4];   // the children's records: four loads in flight, fixed summation order
+        for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
+          if (c0 == 0) for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+        }
+        if (s_nch == 0) for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
+        if (i == j) a += tsq[i];
+      }
+      S[i * CH_LD + j] = a;
+    }
+    if (tid < M) {
+      const int i = tid;
+      double a = 0.0;
+      for (int k = i; k < M; ++k) a -= Ri[(size_t)k * ldN + i] * tv[k];
+      double ch[4];
+      for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      }
+      bv[i] = a + tsq[i] * yx[i];
+    }
+  }
+  STAMP(3);
+  // Gram part of the message records, [ N_a' N_a ] + the children's records (spamtree_model.cpp:1158-1207); it does not
+  // depend on the draw and is skipped while it is still valid for the accepted theta
+  double *rec = A.acc + B0.acc_off;
+  const int nsteps = Mr4 >> 2;
+  if (A.do_gram) {
+    for (int u = wid; u < J * 4; u += NT / 64) {
+      const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
+      const int ma = s_am[t], oa = s_ao[t];
+      if (it * 16 >= ma || jt * 16 >= ma) continue;
+      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+      const double *ap = Np + (size_t)l4 * ldN + oa + it * 16 + l15;
+      const double *bp = Np + (size_t)l4 * ldN + oa + jt * 16 + l15;
+      for (int st = 0; st < nsteps; ++st) {
+        const bool rok = 4 * st + l4 < M;   // rows >= M are not staged; columns past the ancestor's m only feed discarded entries
+        const double av_ = rok ? ap[0] : 0.0, bv_ = rok ? bp[0] : 0.0;
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av_, bv_, c, 0, 0, 0);
+        ap += 4 * ldN; bp += 4 * ldN;
+      }
+      double *out = rec + s_aoff[t];
+      // children's records: all loads of a chunk of four children are issued together (fixed summation order)
+      double chv[4] = {0.0, 0.0, 0.0, 0.0};
+      const int nfw = A.no_fwd ? 0 : s_nch;
+      for (int c0 = 0; c0 < nfw; c0 += 4) {
+        double ld4[4][4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+            ld4[cc][r] = (c0 + cc < nfw && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, nfw - 1)] + s_aoff[t] + i * ma + j] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) chv[r] += ld4[cc][r];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+        if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
+      }
+    }
+  }
+  if (refgrp) {
+    // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I]: two small matrix-vector products
+    // instead of a forward and a backward substitution (m barrier steps each)
+    if (M <= 27) {
+      // one wave, registers only (wave_chol_solve): the other waves wait
+      __syncthreads();   // S, bv complete
+      if (tid < 64) wave_chol_solve<27>(S, bv, zc, wv + P, M, &s_fail, tid);
+    } else {
+      team_chol_eliminate<5, NT>(S, Li, M, M, av, &s_fail, tid);
+      if (tid < M) {
+        double a = zc[tid];
+        for (int j = 0; j <= tid; ++j) a += Li[tid * CH_LD + j] * bv[j];
+        ev[tid] = a;
+      }
+      __syncthreads();
+      if (tid < M) {
+        double a = 0.0;
+        for (int i = tid; i < M; ++i) a += Li[i * CH_LD + tid] * ev[i];
+        wv[P + tid] = a;
+      }
+    }
+  }
+  __syncthreads();
+  STAMP(4);
+  if (refgrp) {
+    const double *Ri = Np + P;
+    if (tid < M) {
+      const int i = tid;
+      A.w[G.row0 + i] = wv[P + i];
+      double a = tv[i];
+      for (int j = 0; j <= i; ++j) a += Ri[(size_t)i * ldN + j] * wv[P + j];
+      ev[i] = a;
+    }
+  } else {
+    if (tid < M) {
+      const int j = tid;
+      const double rj = Np[(size_t)j * ldN + P];
+      const double sig = rj * rj + tsq[j];
+      if (!(sig > 0.0)) s_fail = 1;
+      const double mu = -rj * tv[j] + tsq[j] * yx[j];
+      const double c = 1.0 / sqrt(sig);
+      const double wj = c * c * mu + c * zc[j];
+      wv[P + j] = wj;
+      A.w[G.row0 + j] = wj;
+      ev[j] = rj * wj + tv[j];
+    }
+  }
+  __syncthreads();
+  // av[t][r] = ev[r] - sum_j N[r][oa_t + j] w_a[j]  for every ancestor t
+  for (int idx = tid; idx < J * 32; idx += NT) {
+    const int t = idx >> 5, r = idx & 31;
+    double a = 0.0;
+    if (r < M) {
+      a = ev[r];
+      const double *row = Np + (size_t)r * ldN + s_ao[t];
+      const double *wa = wv + s_ao[t];
+      for (int j = 0; j < s_am[t]; ++j) a -= row[j] * wa[j];
+    }
+    av[idx] = a;
+  }
+  __syncthreads();
+  STAMP(5);
+  // vector part of the records: -N_a' av_a + the children's
+  for (int idx = tid; idx < J * 32; idx += NT) {
+    const int t = idx >> 5, i = idx & 31;
+    const int ma = s_am[t], oa = s_ao[t];
+    if (i < ma) {
+      double a = 0.0;
+      double ch[4];   // the children's vectors: requested before the dot product, added after it in a fixed order
+      const int nch = A.no_fwd ? 0 : s_nch;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
+      for (int r = 0; r < M; ++r) a -= Np[(size_t)r * ldN + oa + i] * av[t * 32 + r];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      for (int c0 = 4; c0 < nch; c0 += 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nch) ? A.acc[s_coff[min(c0 + cc, nch - 1)] + s_aoff[t] + ma * ma + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      }
+      rec[s_aoff[t] + ma * ma + i] = a;
+    }
+  }
+  STAMP(6);
+  STAMP_FLUSH;
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, the theta-only part of the messages on its own: Gram part of a group's records, N_a' N_a + the children's
+// (spamtree_model.cpp:1162, 1190-1192: G_u[a, a]; SURVEY.md Q4: it depends on the accepted theta only).  Launched per level,
+// leaves first, on the first sweep after a factorisation of the accepted slot; the sweep itself then always takes the lean
+// kernels.  The panel is NOT staged: a wave owns one 16 x 16 tile of one ancestor's Gram matrix and reads its MFMA operands
+// straight from global memory / L2 (16 consecutive doubles per panel row and lane group), every load of the tile in
+// flight before the first MFMA; LDS holds the descriptor only, so eight workgroups share a CU.  Same arithmetic and
+// summation order as the Gram section of k_sample_mfma (bit-identical records).
+__global__ __launch_bounds__(NT, 6) void k_gram(SampleFastArgs A) {
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32];
+  __shared__ int s_bld[32];
+  __shared__ long long s_coff[64];
+  __shared__ long long s_gd[GD_MAXW];
+  __shared__ long long s_rowoff[32];   // panel offset of the group's row r
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const int M = B0.M, J = B0.nanc;
+  __syncthreads();
+  if (tid < 32) {
+    long long off = 0;
+    if (tid < M) {
+      const long long r = B0.row0 + tid;
+      int bi = 0;
+      while (bi + 1 < B0.nblk && r >= s_brow[bi + 1]) ++bi;
+      off = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+    }
+    s_rowoff[tid] = off;
+  }
+  __syncthreads();
+  const int nsteps = (M + 3) >> 2;          // <= 8
+  const int nfw = A.no_fwd ? 0 : B0.ndch;
+  double *rec = A.acc + B0.acc_off;
+  for (int u = wid; u < J * 4; u += NT / 64) {
+    const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
+    const int ma = s_am[t], oa = s_ao[t];
+    if (it * 16 >= ma || jt * 16 >= ma) continue;
+    double av_[8], bv_[8];
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int r = 4 * st + l4;
+      const bool rok = st < nsteps && r < M;   // columns past the ancestor's m only feed discarded entries
+      const double *row = A.panels + s_rowoff[min(r, 31)] + oa + l15;
+      av_[st] = rok ? row[it * 16] : 0.0;
+      bv_[st] = rok ? row[jt * 16] : 0.0;
+    }
+    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+      if (st < nsteps) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av_[st], bv_[st], c, 0, 0, 0);
+    double *out = rec + s_aoff[t];
+    double chv[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < nfw; c0 += 4) {   // children's records: chunks of four in flight, fixed summation order
+      double ld4[4][4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+          ld4[cc][r] = (c0 + cc < nfw && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, nfw - 1)] + s_aoff[t] + i * ma + j] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) chv[r] += ld4[cc][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+      if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, fast path, sweeps that keep the cached Gram parts (do_gram == 0: every sweep between two accepted theta).
+// Same results as k_sample_mfma up to rounding, but the panel is never staged in LDS: it is read twice from global
+// memory (L2 / Infinity Cache the second time) with a thread mapping chosen per pass --
+//   pass 1: thread (row r, ancestor t) sums its 25-or-so products N[r][oa_t + j] w_a[j]: the segment sums give both
+//           tv = N w_pa (their sum over t) and, later, av_t = ev - N_t w_t, with no cross-lane reduction;
+//   pass 2: thread k (a chain column) accumulates -sum_r N[r][k] av_t(k)[r]: coalesced rows, no reduction either.
+// LDS holds vectors only (plus the m x m posterior precision of reference blocks): ~6-19 KB instead of 50-55 KB, so
+// 6-8 workgroups share a CU and their latency chains overlap.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
+  __shared__ int s_bld[32], s_cb[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];
+  __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
+
+  const int tid = threadIdx.x;
+  double *wv = lds;                                  // maxP + 32 : ancestors' w, then the group's new w
+  double *seg = wv + A.maxP + 32;                    // av_dbl : seg[t][r], later av[t][r]; elimination scratch in between
+  double *tv = seg + A.av_dbl + 16, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32, *rjv = zc + 32;
+  double *Rc = rjv + 32;                             // reference levels only: Ri, 32 x CH_LD
+  double *S = Rc + 32 * CH_LD;                       // 32 x CH_LD: posterior precision, then its inverse Cholesky factor
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  const bool refgrp = B0.isref != 0;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
+  if (tid >= 32 && tid < 64) {
+    const int j = tid - 32;
+    double t_ = 0.0, y_ = 0.0, z_ = 0.0, r_ = 0.0;
+    int bi = 0;
+    long long ro = 0;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
+      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
+      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
+      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
+      if (!refgrp) r_ = A.panels[ro + P];
+    }
+    tsq[j] = t_; yx[j] = y_; zc[j] = z_; rjv[j] = r_; s_cb[j] = bi; s_rowoff[j] = ro;
+  }
+  __syncthreads();
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+  }
+  if (refgrp) {   // Ri -> LDS (rows of the panel's last M columns)
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      Rc[i * CH_LD + j] = (j <= i) ? A.panels[s_rowoff[i] + P + j] : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
+  for (int idx = tid; idx < M * J; idx += NT) {
+    const int r = idx / J, t = idx - r * J;
+    const int ma = s_am[t], oa = s_ao[t];
+    const double *row = A.panels + s_rowoff[r] + oa;
+    const double *wa = wv + oa;
+    double a = 0.0;
+    for (int j0 = 0; j0 < ma; j0 += 16) {   // two batches of loads for the usual 25-row ancestor
+      double x[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+    }
+    seg[t * 32 + r] = a;
+  }
+  __syncthreads();
+  if (tid < M) {
+    double a = 0.0;
+    for (int t = 0; t < J; ++t) a += seg[t * 32 + tid];
+    tv[tid] = a;
+  }
+  __syncthreads();
+  if (refgrp) {
+    for (int idx = tid; idx < M * M; idx += NT) {
+      const int i = idx / M, j = idx - i * M;
+      double a = 0.0;
+      if (j <= i) {
+        double ch[4];   // the children's records: four loads in flight, fixed summation order
+        for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
+          if (c0 == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+        }
+        if (s_nch == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
+        if (i == j) a += tsq[i];
+      }
+      S[i * CH_LD + j] = a;
+    }
+    if (tid < M) {
+      const int i = tid;
+      double a = 0.0;
+      for (int k = i; k < M; ++k) a -= Rc[k * CH_LD + i] * tv[k];
+      double ch[4];
+      for (int c0 = 0; c0 < s_nch; c0 += 4) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+      }
+      bv[i] = a + tsq[i] * yx[i];
+    }
+    // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I] (scratch: the pivot cells live after
+    // the segment sums, which stay intact)
+    double *pub = seg + 32 * J;
+    if (M <= 27) {
+      // one wave, registers only: elimination with the right-hand side riding along, backward substitution by wave sums
+      __syncthreads();   // S, bv complete
+      if (tid < 64) wave_chol_solve<27>(S, bv, zc, wv + P, M, &s_fail, tid);
+      __syncthreads();
+    } else {
+      team_chol_eliminate<5, NT>(S, S, M, M, pub, &s_fail, tid);
+      if (tid < M) {
+        double a = zc[tid];
+        for (int j = 0; j <= tid; ++j) a += S[tid * CH_LD + j] * bv[j];
+        ev[tid] = a;
+      }
+      __syncthreads();
+      if (tid < M) {
+        double a = 0.0;
+        for (int i = tid; i < M; ++i) a += S[i * CH_LD + tid] * ev[i];
+        wv[P + tid] = a;
+      }
+      __syncthreads();
+    }
+    if (tid < M) {
+      const int i = tid;
+      A.w[G.row0 + i] = wv[P + i];
+      double a = tv[i];
+      for (int j = 0; j <= i; ++j) a += Rc[i * CH_LD + j] * wv[P + j];
+      ev[i] = a;
+    }
+  } else {
+    if (tid < M) {
+      const int j = tid;
+      const double rj = rjv[j];
+      const double sig = rj * rj + tsq[j];
+      if (!(sig > 0.0)) s_fail = 1;
+      const double mu = -rj * tv[j] + tsq[j] * yx[j];
+      const double c = 1.0 / sqrt(sig);
+      const double wj = c * c * mu + c * zc[j];
+      A.w[G.row0 + j] = wj;
+      ev[j] = rj * wj + tv[j];
+    }
+  }
+  __syncthreads();
+  // av[t][r] = ev[r] - seg[t][r]
+  for (int idx = tid; idx < J * 32; idx += NT) {
+    const int r = idx & 31;
+    seg[idx] = (r < M) ? ev[r] - seg[idx] : 0.0;
+  }
+  __syncthreads();
+  // ---- pass 2: vector part of the records, -N_a' av_a + the children's
+  double *rec = A.acc + B0.acc_off;
+  for (int k = tid; k < P; k += NT) {
+    int t = 0;
+    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+    const int ma = s_am[t], i = k - s_ao[t];
+    const double *avt = seg + t * 32;
+    double ch[4];   // the children's vectors: requested first, added after the dot product in a fixed order
+    const int nch = A.no_fwd ? 0 : s_nch;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
+    double a = 0.0;
+    for (int r0 = 0; r0 < M; r0 += 8) {
+      double x[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < M) ? A.panels[s_rowoff[min(r0 + rr, M - 1)] + k] : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) a -= x[rr] * avt[min(r0 + rr, 31)];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+    for (int c0 = 4; c0 < nch; c0 += 4) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nch) ? A.acc[s_coff[min(c0 + cc, nch - 1)] + s_aoff[t] + ma * ma + i] : 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+    }
+    rec[s_aoff[t] + ma * ma + i] = a;
+  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, reference blocks of at most 27 rows, ONE BLOCK PER WAVE (four independent blocks per workgroup, no workgroup
+// barrier anywhere).  k_sample_lean gives a block 256 threads and eleven barriers for what is a chain of short dependent
+// steps (descriptor -> rows' data -> panel pass 1 -> children's records -> 25-pivot solve -> panel pass 2): a 55 us latency
+// chain per block with five of them in flight per CU.  Here a wave walks the same chain alone -- lane i owns row i: its
+// segment sums, row i of the posterior precision built straight into the registers the elimination works on
+// (wave_chol_solve_core), its draw -- with 11 KB of LDS, so twelve blocks are in flight per CU.  Same arithmetic and
+// summation orders as k_sample_lean (identical draws).  LDS operations of one wave execute in order: a wave-level
+// s_waitcnt separates the phases.
+// ---------------------------------------------------------------------------------------------------------------
+#define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_failw[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int gidx = blockIdx.x * (NT / 64) + wid;
+  if (gidx >= A.ngrp) return;   // no workgroup barrier below: a wave without a block simply leaves
+  double *base = lds + (size_t)wid * A.ldN;          // this wave's LDS region (A.ldN doubles)
+  long long *s_gd = (long long *)base;               // the block's descriptor
+  double *wv = base + A.gd_stride;                   // maxP + 32 : ancestors' w, then the block's new w
+  double *seg = wv + A.maxP + 32;                    // av_dbl : seg[t][r], later av[t][r]
+  double *tv = seg + A.av_dbl, *ev = tv + 32;
+  double *Rc = ev + 32;                              // Mrows x CH_LD: Ri
+  if (lane == 0) s_failw[wid] = 0;
+  for (int i = lane; i < A.gd_stride; i += 64) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
+  WSYNC();
+  auto slo = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)); };
+  auto shi = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v >> 32)); };
+  auto sll = [&](long long v) { return ((long long)shi(v) << 32) | (unsigned int)slo(v); };
+  const long long row0 = sll(s_gd[0]), acc_off = sll(s_gd[1]);
+  const int M = slo(s_gd[2]), P = shi(s_gd[2]), J = slo(s_gd[3]), level = shi(s_gd[4]);
+  const int nch = slo(s_gd[5]), acc_len = shi(s_gd[5]);
+  const long long *gb = s_gd + 8 + 4 * J;            // the block: panel offset, first row, ld
+  const long long bpan = sll(gb[0]);
+  const int bld = (int)sll(gb[2]);
+  const long long *coff = gb + 3;                    // message records of the direct children
+  auto am_of = [&](int t) { return (int)(s_gd[8 + 4 * t] & 0xffffffffLL); };
+  auto ao_of = [&](int t) { return (int)(s_gd[8 + 4 * t] >> 32); };
+  const bool row = lane < M;
+  const int li = min(lane, 31);
+  double tsq = 0.0, yx = 0.0, zc = 0.0;
+  if (row) { const long long r = row0 + lane; tsq = A.tausq_inv[A.mv[r]]; yx = A.y[r] - A.xb[r]; zc = A.z[r]; }
+  for (int k = lane; k < P; k += 64) {
+    int t = 0;
+    for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
+    wv[k] = A.w[s_gd[8 + 4 * t + 1] + (k - ao_of(t))];
+  }
+  for (int idx = lane; idx < M * M; idx += 64) {     // Ri -> LDS (the panel's last M columns)
+    const int i = idx / M, j = idx - i * M;
+    Rc[i * CH_LD + j] = (j <= i) ? A.panels[bpan + (size_t)i * bld + P + j] : 0.0;
+  }
+  WSYNC();
+  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
+  for (int idx = lane; idx < M * J; idx += 64) {
+    const int r = idx / J, t = idx - r * J;
+    const int ma = am_of(t), oa = ao_of(t);
+    const double *prow = A.panels + bpan + (size_t)r * bld + oa;
+    const double *wa = wv + oa;
+    double a = 0.0;
+    for (int j0 = 0; j0 < ma; j0 += 16) {
+      double x[16];
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) x[jj] = (j0 + jj < ma) ? prow[j0 + jj] : 0.0;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
+    }
+    seg[t * 32 + r] = a;
+  }
+  WSYNC();
+  double tvi = 0.0;
+  if (row) { for (int t = 0; t < J; ++t) tvi += seg[t * 32 + lane]; tv[lane] = tvi; }
+  WSYNC();
+  // ---- row `lane` of the posterior precision Ri'Ri + the children's Gram parts + tausq_inv, straight into registers
+  double a[27];
+#pragma unroll
+  for (int j = 0; j < 27; ++j) a[j] = 0.0;
+  double bv = 0.0;
+  for (int k = 0; k < M; ++k) {                      // Ri[k][i] = 0 for k < i: the leading terms add exact zeros
+    const double rk = Rc[k * CH_LD + li];
+    bv -= rk * tv[k];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) a[j] += rk * Rc[k * CH_LD + j];
+  }
+  for (int c = 0; c < nch; ++c) {                    // the children's records, fixed order
+    const double *rc = A.acc + coff[c] + acc_len;
+    double ch[27];
+#pragma unroll
+    for (int j = 0; j < 27; ++j) ch[j] = (row && j <= lane) ? rc[li * M + j] : 0.0;
+    const double cv = row ? rc[M * M + li] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) a[j] += ch[j];
+    bv += cv;
+  }
+#pragma unroll
+  for (int j = 0; j < 27; ++j) {
+    if (j == lane) a[j] += tsq;
+    a[j] = (row && j <= lane) ? a[j] : (j == lane ? 1.0 : 0.0);
+  }
+  bv = row ? bv + tsq * yx : 0.0;
+  // ---- w_u = L^{-T} (L^{-1} b + z): elimination with the right-hand side riding along, backward substitution by wave sums
+  const double wnew = wave_chol_solve_core<27>(a, bv, zc, M, &s_failw[wid], lane);
+  if (row) { A.w[row0 + lane] = wnew; wv[P + lane] = wnew; }
+  WSYNC();
+  if (row) {
+    double e = tvi;
+    for (int j = 0; j <= lane; ++j) e += Rc[lane * CH_LD + j] * wv[P + j];
+    ev[lane] = e;
+  }
+  WSYNC();
+  for (int idx = lane; idx < J * 32; idx += 64) {    // av[t][r] = ev[r] - seg[t][r]
+    const int r = idx & 31;
+    seg[idx] = (r < M) ? ev[r] - seg[idx] : 0.0;
+  }
+  WSYNC();
+  // ---- pass 2: vector part of the records, -N_a' av_a + the children's
+  double *rec = A.acc + acc_off;
+  const int nfw = A.no_fwd ? 0 : nch;
+  for (int k = lane; k < P; k += 64) {
+    int t = 0;
+    for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
+    const int ma = am_of(t), i = k - ao_of(t);
+    const long long aoff = s_gd[8 + 4 * t + 3];
+    const double *avt = seg + t * 32;
+    double ch[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nfw) ? A.acc[coff[min(cc, max(nfw - 1, 0))] + aoff + ma * ma + i] : 0.0;
+    double acc = 0.0;
+    for (int r0 = 0; r0 < M; r0 += 8) {
+      double x[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < M) ? A.panels[bpan + (size_t)min(r0 + rr, M - 1) * bld + k] : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) acc -= x[rr] * avt[min(r0 + rr, 31)];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) acc += ch[cc];
+    for (int c0 = 4; c0 < nfw; c0 += 4) {
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nfw) ? A.acc[coff[min(c0 + cc, nfw - 1)] + aoff + ma * ma + i] : 0.0;
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) acc += ch[cc];
+    }
+    rec[aoff + ma * ma + i] = acc;
+  }
+  WSYNC();
+  if (lane == 0 && s_failw[wid]) atomicMin(A.errflag, level * 16 + 10);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, fast path, leaf (non-reference) groups on sweeps that keep the cached Gram parts.  The rows of a leaf group
+// are independent given the ancestors (diagonal Ri), so a wave owns whole rows: lanes hold the row's columns (coalesced
+// loads, registers only), the per-ancestor segment sums come from masked butterfly reductions, the draw, the residual
+// and the row's contribution -N[r][k] av_t(k)[r] to every chain column follow without leaving the wave; only the
+// column sums over the four waves go through LDS.  One pass over the panel, ~10 KB of LDS, one barrier pair.
+// ---------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
+  __shared__ int s_bld[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];
+  __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
+  __shared__ double s_seg[NT / 64][MAXJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *wv = lds;                       // maxP + 32
+  double *red = wv + A.maxP + 32;         // 4 x 256: per-wave column sums
+  double *tsq = red + 4 * 256, *yx = tsq + 32, *zc = yx + 32;
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
+  if (tid >= 32 && tid < 64) {
+    const int j = tid - 32;
+    double t_ = 0.0, y_ = 0.0, z_ = 0.0;
+    long long ro = 0;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
+      int bi = 0;
+      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
+      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
+      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
+    }
+    tsq[j] = t_; yx[j] = y_; zc[j] = z_; s_rowoff[j] = ro;
+  }
+  __syncthreads();
+  // this lane's columns k = lane + 64 c (P + 1 <= 256 columns: the host routes longer chains to k_sample_mfma)
+  int tk[4];
+  double wk[4], acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int k = lane + 64 * c;
+    const int t = anc_of(s_ao, J, k);
+    tk[c] = k < P ? t : -1;
+    wk[c] = k < P ? A.w[s_arow[t] + (k - s_ao[t])] : 0.0;
+    acc[c] = 0.0;
+  }
+  const int lastc = P >> 6, lastl = P & 63;   // where column P (the row's r_j) lives
+#pragma unroll 1
+  for (int b = 0; b < 2; ++b) {
+    double v[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      const double *src = A.panels + s_rowoff[min(j, M - 1)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int k = lane + 64 * c;
+        v[rr][c] = (j < M && k <= P) ? src[k] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      if (j < M) {   // wave-uniform
+        // segment sums (every lane gets them), tv = their sum in ancestor order
+        double tvj = 0.0;
+        for (int t = 0; t < J; ++t) {
+          double x = 0.0;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x += (tk[c] == t) ? v[rr][c] * wk[c] : 0.0;
+          x = wave_allsum(x);
+          if (lane == 0) s_seg[wid][t] = x;
+          tvj += x;
+        }
+        double rj = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c == lastc) rj = __shfl(v[rr][c], lastl, 64);
+        const double sig = rj * rj + tsq[j];
+        if (!(sig > 0.0) && lane == 0) s_fail = 1;
+        const double mu = -rj * tvj + tsq[j] * yx[j];
+        const double cc = 1.0 / sqrt(sig);
+        const double wj = cc * cc * mu + cc * zc[j];
+        if (lane == 0) A.w[G.row0 + j] = wj;
+        const double evj = rj * wj + tvj;
+        // this row's share of the vector records: -N[j][k] (ev_j - seg_t(k)[j])
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (tk[c] >= 0) acc[c] -= v[rr][c] * (evj - s_seg[wid][tk[c]]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) red[wid * 256 + lane + 64 * c] = acc[c];
+  __syncthreads();
+  double *rec = A.acc + B0.acc_off;
+  for (int k = tid; k < P; k += NT) {
+    const int t = anc_of(s_ao, J, k);
+    const int ma = s_am[t], i = k - s_ao[t];
+    double a = ((red[k] + red[256 + k]) + red[512 + k]) + red[768 + k];
+    for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
+    rec[s_aoff[t] + ma * ma + i] = a;
+  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 11);
+}
+
+template __global__ void k_sample<false, false>(SampleArgs);
+template __global__ void k_sample<true, false>(SampleArgs);
+template __global__ void k_sample<true, true>(SampleArgs);
+#else   // host side: prototypes only (the kernels are compiled in their own translation unit)
+template <bool BIG, bool NOREF = false> __global__ void k_sample(SampleArgs A);
+__global__ void k_gram_big(GramBigArgs A);
+__global__ void k_sample_mfma(SampleFastArgs A);
+__global__ void k_gram(SampleFastArgs A);
+__global__ void k_sample_lean(SampleFastArgs A);
+__global__ void k_sample_wave(SampleFastArgs A);
+__global__ void k_sample_leaf(SampleFastArgs A);
+#endif

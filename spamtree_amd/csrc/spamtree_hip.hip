@@ -17,3023 +17,21 @@
 //   R = K_uu - V'V,  Ri = chol(R)^{-1},  panel_u = [-Ri*T | Ri]
 // Messages to ancestors are pushed as per-ancestor (m_a x m_a, m_a) pairs and summed hierarchically through
 // direct children in a fixed order (no FP64 atomics -> bit-reproducible for any launch geometry).
-#include <hip/hip_runtime.h>
+//
+// This translation unit is the HOST side: handle, C-ABI, launches.  The kernels live in one translation unit per family
+// (k_factor_generic.hip, k_factor_mfma.hip, k_factor_quad.hip, k_factor_wide.hip, k_sample.hip, k_misc.hip); the headers
+// included here give their argument structures, launch constants and prototypes.
 
-#include <algorithm>
-#include <climits>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "spamtree_hip.h"
-#include <rccl/rccl.h>
-
-#define NT 256
-#define MAXJ ST_MAX_ANCESTORS
-#define QMAX ST_MAX_Q
-#define HL2PI (-0.91893853320467274178032973640562)
-
-struct CovPar {
-  int q;
-  int ncb;
-  double ai1[QMAX], ai2[QMAX], phi[QMAX];
-  double tmv[3];
-  double D[QMAX * QMAX];
-  // per pair of outcomes, filled on the host (finish_covpar): everything of the Apanasovich-Genton form that does not
-  // depend on the distance.  cov = amp exp(-rate h) [+ amp2 exp(-phi[vi] h) where the Dmat entry is exactly zero]
-  double rate[QMAX * QMAX], amp[QMAX * QMAX], amp2[QMAX * QMAX];
-};
-
-struct Blk {
-  long long row0;       // first device row
-  long long panel_off;  // doubles, into a slot's panel arena (-1: none)
-  long long acc_off;    // doubles, into the message arena
-  int m, P, nanc, anc_ptr;
-  int isref, nobs, dch_ptr, ndch;
-  int acc_len, level, ld, model_id;   // acc_len: on the device = offset of the children's records FOR this block inside their records
-  long long chain_off;  // panel the DESCENDANTS read as this block's rows of their chain factor: = panel_off, or (limited_tree)
-                        // the block's marginal inverse Cholesky chol(K_uu)^{-1}, m x m (k_marginal_invchol)
-};
-
-// ---------------------------------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------------------------------
-// exp(x) for the covariance kernels: two-step Cody-Waite reduction to |r| <= ln2/2, degree-13 Taylor polynomial in
-// Estrin form (truncation error < 5e-18; short dependency chains, no register copies), v_ldexp_f64 for the scaling
-// (overflow -> inf, underflow -> denormals / 0 as in libm).  Under half the instructions of the library routine;
-// relative error < 3e-16.
-__device__ __forceinline__ double cov_exp(double x) {
-  x = fmax(x, -1500.0);
-  const double t = __builtin_rint(x * 1.44269504088896338700e+00);
-  double r = fma(t, -6.93147180369123816490e-01, x);
-  r = fma(t, -1.90821492927058770002e-10, r);
-  const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
-  const double a0 = 1.0 + r;
-  const double a1 = fma(1.6666666666666666e-01, r, 0.5);                         // 1/3!, 1/2!
-  const double a2 = fma(8.3333333333333332e-03, r, 4.1666666666666664e-02);      // 1/5!, 1/4!
-  const double a3 = fma(1.9841269841269841e-04, r, 1.3888888888888889e-03);      // 1/7!, 1/6!
-  const double a4 = fma(2.7557319223985893e-06, r, 2.4801587301587302e-05);      // 1/9!, 1/8!
-  const double a5 = fma(2.5052108385441720e-08, r, 2.7557319223985888e-07);      // 1/11!, 1/10!
-  const double a6 = fma(1.6059043836821613e-10, r, 2.0876756987868100e-09);      // 1/13!, 1/12!
-  const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2), b2 = fma(a5, r2, a4);
-  const double d0 = fma(b1, r4, b0), d1 = fma(a6, r4, b2);
-  const double p = fma(d1, r8, d0);
-  return __builtin_ldexp(p, (int)t);   // |t| < 2^31 after the clamp above, or +huge -> saturating conversion -> inf
-}
-
-// exp(x) with a 64-entry table of 2^(j/64) (in LDS: EXP2_64 copied by the kernel), for the covariance pass of k_factor_quad,
-// which runs at the FP64 pipe's issue rate (44 FP64 instructions per entry, 4 cycles each, stamps of round 3): the reduced
-// argument is |r| <= ln2/128, so a degree-5 polynomial is exact to 3.5e-17 and the whole exponential costs 16 FP64
-// instructions + one LDS read instead of 24.  x = t ln2/64 + r, t = 64 k + j: exp(x) = 2^k 2^(j/64) e^r.  Relative error
-// < 3e-16 (the table entries are correctly rounded); over- / underflow as cov_exp.
-__device__ const double EXP2_64[64] = {
-  0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
-  0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
-  0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
-  0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
-  0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
-  0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
-  0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
-  0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
-  0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
-  0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
-  0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
-  0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
-  0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
-  0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
-  0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-  0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
-};
-__device__ __forceinline__ double cov_exp_tab(double x, const double *tab) {
-  x = fmax(x, -1500.0);
-  const double t = __builtin_rint(x * 9.233248261689366e+01);          // 64 / ln 2
-  double r = fma(t, -1.08304246932675596327e-02, x);                   // ln2 / 64: the 32-bit head of cov_exp's split, scaled
-  r = fma(t, -2.98158582698529328128e-12, r);
-  const int ti = (int)t;
-  const double T = tab[ti & 63];
-  const double r2 = r * r;
-  const double a0 = 1.0 + r;
-  const double a1 = fma(1.6666666666666666e-01, r, 0.5);
-  const double a2 = fma(8.3333333333333332e-03, r, 4.1666666666666664e-02);
-  const double p = fma(fma(a2, r2, a1), r2, a0);
-  return __builtin_ldexp(p * T, ti >> 6);
-}
-
-// sqrt(a) for squared distances (a >= 0): v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections (the
-// library's scheme without its range scaling).  a is clamped to 1e-300 from below, so coincident points give 1e-150
-// instead of 0 (exp(-phi * 1e-150) == 1 exactly); squared distances above ~1e300 are outside the contract.
-__device__ __forceinline__ double cov_sqrt(double a) {
-  a = fmax(a, 1e-300);
-  const double y = __builtin_amdgcn_rsq(a);
-  double g = a * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  double d = fma(-g, g, a);
-  g = fma(d, h, g);
-  d = fma(-g, g, a);
-  return fma(d, h, g);
-}
-
-__device__ __forceinline__ double cov_entry(const CovPar &c, double xi, double yi, int vi, double xj, double yj, int vj) {
-  const double dx = xi - xj, dy = yi - yj;
-  const double h = cov_sqrt(dx * dx + dy * dy);
-  if (c.q == 1) return c.ai1[0] * cov_exp(-c.tmv[0] * h);  // cexpcov: sigmasq = ai1(0), phi = thetamv(0)
-  // mvCovAG20107 (covariance_functions.cpp:213-286): C_base(h, 0, v) = exp(-c h / psi) / psi^2 with psi = (a v + 1)^(b/2)
-  // (q > 2) or exp(-c h / sqrt(v + 1)) / (v + 1) (q = 2); psi, the amplitudes and the v == 0 case are per outcome pair
-  const int ij = vi * c.q + vj;
-  double r = c.amp[ij] * cov_exp(-c.rate[ij] * h);
-  const double a2 = c.amp2[ij];
-  if (a2 != 0.0) r += a2 * cov_exp(-c.phi[vi] * h);
-  return r;
-}
-
-__device__ __forceinline__ double cov_entry_tab(const CovPar &c, const double *tab, double xi, double yi, int vi, double xj, double yj, int vj) {
-  const double dx = xi - xj, dy = yi - yj;
-  const double h = cov_sqrt(dx * dx + dy * dy);
-  if (c.q == 1) return c.ai1[0] * cov_exp_tab(-c.tmv[0] * h, tab);
-  const int ij = vi * c.q + vj;
-  double r = c.amp[ij] * cov_exp_tab(-c.rate[ij] * h, tab);
-  const double a2 = c.amp2[ij];
-  if (a2 != 0.0) r += a2 * cov_exp_tab(-c.phi[vi] * h, tab);
-  return r;
-}
-
-// host: the distance-independent parts of the multivariate form
-static void finish_covpar(CovPar *c) {
-  const int q = c->q;
-  for (int vi = 0; vi < q; ++vi)
-    for (int vj = 0; vj < q; ++vj) {
-      const int ij = vi * q + vj;
-      const double v = c->D[ij];
-      double rate, den;
-      if (q > 2) {
-        const double ps = std::exp(0.5 * c->tmv[1] * std::log1p(c->tmv[0] * v));
-        rate = c->tmv[2] / ps; den = ps * ps;
-      } else {
-        const double ps = std::sqrt(v + 1.0);
-        rate = c->tmv[0] / ps; den = v + 1.0;
-      }
-      c->rate[ij] = rate;
-      if (v == 0.0) { c->amp[ij] = c->ai1[vi] * c->ai1[vi] / den; c->amp2[ij] = c->ai2[vi] * c->ai2[vi]; }
-      else { c->amp[ij] = c->ai1[vi] * c->ai1[vj] / den; c->amp2[ij] = 0.0; }
-    }
-}
-
-// the ancestor whose rows hold chain row k (s_ao ascending, s_ao[0] = 0): independent compares -- a search loop is a chain of
-// dependent LDS reads on every block's latency path
-__device__ __forceinline__ int anc_of(const int *s_ao, int J, int k) {
-  int t = 0;
-#pragma unroll
-  for (int j = 1; j < 8; ++j) t += (j < J && k >= s_ao[j]) ? 1 : 0;
-  for (int j = 8; j < J; ++j) t += (k >= s_ao[j]) ? 1 : 0;
-  return t;
-}
-
-// workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for global loads in flight
-// (a prefetched sub-panel keeps travelling across it) nor for global stores
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
-}
-
-// block-wide sum of one double per thread; result valid in every thread. red: >= NT/64 doubles of LDS.
-__device__ __forceinline__ double block_sum(double v, double *red) {
-  v = wave_sum(v);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) red[wv] = v;
-  __syncthreads();
-  double s = 0.0;
-  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
-  return s;
-}
-
-// In-place lower Cholesky of the m x m row-major matrix A (lower triangle referenced).  *fail set when a pivot
-// is not > 0 (LAPACK dpotrf's test, NaN included).  All threads of the block must call.
-__device__ void chol_lower_inplace(double *A, int m, int *fail) {
-  for (int k = 0; k < m; ++k) {
-    __syncthreads();
-    const double d = A[k * m + k];
-    if (!(d > 0.0)) {
-      if (threadIdx.x == 0) *fail = 1;
-    }
-    const double piv = sqrt(d);
-    __syncthreads();
-    for (int i = k + threadIdx.x; i < m; i += blockDim.x) A[i * m + k] = (i == k) ? piv : A[i * m + k] / piv;
-    __syncthreads();
-    const int r = m - k - 1;
-    for (int idx = threadIdx.x; idx < r * r; idx += blockDim.x) {
-      const int i = k + 1 + idx / r, j = k + 1 + idx % r;
-      if (j <= i) A[i * m + j] -= A[i * m + k] * A[j * m + k];
-    }
-  }
-  __syncthreads();
-}
-
-// Ri = L^{-1} (lower, zeros above the diagonal), one thread per column.
-__device__ void tri_inverse_lower(const double *L, double *Ri, int m) {
-  for (int j = threadIdx.x; j < m; j += blockDim.x) {
-    for (int i = 0; i < j; ++i) Ri[i * m + j] = 0.0;
-    for (int i = j; i < m; ++i) {
-      double s = (i == j) ? 1.0 : 0.0;
-      for (int k = j; k < i; ++k) s -= L[i * m + k] * Ri[k * m + j];
-      Ri[i * m + j] = s / L[i * m + i];
-    }
-  }
-  __syncthreads();
-}
-
-// Ri = chol(A)^{-1} for an m x m matrix in LDS (row-major, stride m, lower triangle referenced; A is destroyed), by the
-// whole workgroup with ONE barrier per pivot: the symmetric elimination of [A | I] (A = L~ D L~', row i of I becomes row i of
-// L~^{-1}), then Ri = D^{-1/2} L~^{-1} -- the scheme of wave_chol_eliminate for blocks too wide for one wave's registers
-// (75-row blocks of the default multivariate tree).  chol_lower_inplace + tri_inverse_lower cost three barriers per pivot
-// and then one THREAD per column of the inverse: 23-29 % of a reference level of config #4 (profiles/r02).
-// *fail set when a pivot is not > 0.  All threads of the block must call; Ri must not alias A.
-__device__ void block_chol_invert(double *A, double *Ri, int m, int *fail) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int idx = tid; idx < m * m; idx += nt) { const int i = idx / m, j = idx - i * m; Ri[idx] = (i == j) ? 1.0 : 0.0; }
-  __syncthreads();
-  const int tj = tid & 31, ti = tid >> 5, nti = nt >> 5;
-  for (int k = 0; k < m; ++k) {
-    const double d = A[k * m + k];
-    if (!(d > 0.0) && tid == 0) *fail = 1;
-    const double rd = 1.0 / d;
-    for (int i = k + 1 + ti; i < m; i += nti) {
-      const double f = -A[i * m + k] * rd;
-      for (int j = tj; j <= i; j += 32) {
-        if (j <= k) Ri[i * m + j] = fma(f, Ri[k * m + j], Ri[i * m + j]);      // row k of the identity part is final
-        else A[i * m + j] = fma(f, A[j * m + k], A[i * m + j]);                // A[k][j] = A[j][k]: column k is not written in this step
-      }
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < m * m; idx += nt) {
-    const int i = idx / m, j = idx - i * m;
-    if (j <= i) Ri[idx] *= rsqrt(A[i * m + i]);
-  }
-  __syncthreads();
-}
-
-// Philox4x32-10 (Salmon et al. 2011) -- same stream contract as oracle.StRng
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned out[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
-    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ double u01(unsigned a, unsigned b) {
-  return ((double)(((unsigned long long)(a >> 5) << 26) + (unsigned long long)(b >> 6)) + 0.5) * (1.0 / 9007199254740992.0);
-}
-__device__ __forceinline__ double philox_normal(unsigned long long idx, unsigned iter, unsigned stream, unsigned long long seed) {
-  unsigned o[4];
-  philox4x32_10((unsigned)idx, (unsigned)(idx >> 32), iter, stream, (unsigned)seed, (unsigned)(seed >> 32), o);
-  const double u1 = u01(o[0], o[1]), u2 = u01(o[2], o[3]);
-  return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
-}
-
-__global__ void k_normals(double *z, const long long *dev2model, long long n, unsigned iter, unsigned stream, unsigned long long seed) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) z[i] = philox_normal((unsigned long long)dev2model[i], iter, stream, seed);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase A / P : per block, one workgroup.  BIG=false keeps K/V, T, the row stage and the m x m factors in LDS;
-// BIG=true keeps them in a per-workgroup slice of a global scratch arena (any m, P).
-// ---------------------------------------------------------------------------------------------------------------
-struct FactorArgs {
-  const Blk *blks;
-  const int *anc_idx;
-  const int *list;  // device block ids to process
-  int nlist;
-  const double *cx, *cy;
-  const int *mv;
-  const double *w_in;   // current w (device order)
-  double *w_out;        // predict: where samples go
-  const double *z;      // predict: normals (device order)
-  double *panels;       // slot arena
-  double *logdet_c, *loglik_c;
-  int *errflag;         // atomicMin(level*16 + code)
-  double *scratch;      // BIG
-  long long scratch_stride;
-  int maxP, maxM, maxMa, SR;
-};
-
-#define MODE_FACTOR 0
-#define MODE_PREDICT 1
-
-// limited_tree (/root/reference/src/spamtree_model.cpp:901-903, 1275-1278: Kxx_inv(u) = inv_sympd(K_uu), every block has
-// ONE parent, /root/reference/src/tree_dep.cpp:133-186): the chain factor the children of u work with is the block's MARGINAL
-// inverse Cholesky chol(K_uu)^{-1} (m x m, row-major, Blk::chain_off), not its conditional panel.  One workgroup per block.
-struct MarginalArgs {
-  const Blk *blks;
-  const int *list;
-  int nlist;
-  const double *cx, *cy;
-  const int *mv;
-  double *panels;
-  int *errflag;
-  int maxM;
-};
-__global__ __launch_bounds__(NT) void k_marginal_invchol(MarginalArgs A, CovPar cp) {
-  extern __shared__ double lds[];   // K (m x m) | L^{-1} (m x m)
-  __shared__ int s_fail;
-  const int tid = threadIdx.x;
-  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
-    const Blk B = A.blks[A.list[li]];
-    const int m = B.m;
-    double *K = lds, *Li = lds + (size_t)A.maxM * A.maxM;
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    for (int idx = tid; idx < m * m; idx += NT) {
-      const int i = idx / m, j = idx - i * m;
-      const long long ri = B.row0 + i, rj = B.row0 + j;
-      K[idx] = (j <= i) ? cov_entry(cp, A.cx[ri], A.cy[ri], A.mv[ri], A.cx[rj], A.cy[rj], A.mv[rj]) : 0.0;
-    }
-    __syncthreads();
-    chol_lower_inplace(K, m, &s_fail);
-    tri_inverse_lower(K, Li, m);
-    double *out = A.panels + B.chain_off;
-    for (int idx = tid; idx < m * m; idx += NT) {
-      const int i = idx / m, j = idx - i * m;
-      out[idx] = (j <= i) ? Li[idx] : 0.0;
-    }
-    if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + 2);   // errtype 2 (:919), reported at the block's level
-    __syncthreads();
-  }
-}
-
-template <bool BIG, int MODE>
-__global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
-  extern __shared__ double lds[];
-  __shared__ int s_anc[MAXJ], s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
-  __shared__ int s_fail;
-  __shared__ double s_red[NT / 64];
-
-  const int tid = threadIdx.x;
-  const int maxP = A.maxP, maxM = A.maxM, maxMa = A.maxMa, SR = A.SR;
-  // LDS carve
-  double *sx = lds;
-  double *sy = sx + (maxP + maxM);
-  double *wv = sy + (maxP + maxM);
-  double *hv = wv + (maxP + maxM);     // maxM
-  double *ev = hv + maxM;              // maxM
-  double *rd = ev + maxM;              // maxM
-  double *stage = rd + maxM;           // SR * maxP
-  int *smv = (int *)(stage + (size_t)SR * maxP);
-  double *big0 = (double *)(smv + ((maxP + maxM + 1) & ~1));
-  double *KV, *Tt, *Vp, *R, *Ri;
-  if (BIG) {
-    double *g = A.scratch + (size_t)blockIdx.x * A.scratch_stride;
-    KV = g; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
-  } else {
-    KV = big0; Tt = KV + (size_t)maxP * maxM; Vp = Tt + (size_t)maxP * maxM; R = Vp + (size_t)maxMa * maxM; Ri = R + (size_t)maxM * maxM;
-  }
-
-  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
-    const int b = A.list[li];
-    const Blk B = A.blks[b];
-    const int m = B.m, P = B.P, J = B.nanc;
-    __syncthreads();
-    if (tid < J) {
-      const int a = A.anc_idx[B.anc_ptr + tid];
-      s_anc[tid] = a;
-      s_am[tid] = A.blks[a].m;
-      s_arow[tid] = A.blks[a].row0;
-      s_apan[tid] = A.blks[a].chain_off;
-    }
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-      s_ao[J] = o;
-    }
-    __syncthreads();
-    for (int t = 0; t < J; ++t) {
-      const long long r0 = s_arow[t];
-      const int oa = s_ao[t];
-      for (int i = tid; i < s_am[t]; i += NT) {
-        sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i];
-      }
-    }
-    for (int i = tid; i < m; i += NT) {
-      sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
-    }
-    __syncthreads();
-    // K_{pa,u}  (covariance_functions.cpp:95-111 / :213-286), T = 0
-    for (int idx = tid; idx < P * m; idx += NT) {
-      const int k = idx / m, j = idx - k * m;
-      KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
-      Tt[idx] = 0.0;
-    }
-    __syncthreads();
-    // one pass over the ancestor chain, last ancestor first
-    for (int t = J - 1; t >= 0; --t) {
-      const int ma = s_am[t], oa = s_ao[t], Kb = oa + ma;
-      const double *pa = A.panels + s_apan[t];
-      for (int r0 = 0; r0 < ma; r0 += SR) {
-        const int sr = min(SR, ma - r0);
-        const double *src = pa + (size_t)r0 * Kb;
-        for (int idx = tid; idx < sr * Kb; idx += NT) stage[idx] = src[idx];
-        __syncthreads();
-        for (int idx = tid; idx < sr * m; idx += NT) {
-          const int i = idx / m, j = idx - i * m;
-          const double *srow = stage + i * Kb;
-          double acc = 0.0;
-          for (int k = 0; k < Kb; ++k) acc += srow[k] * KV[k * m + j];
-          Vp[(r0 + i) * m + j] = acc;
-        }
-        __syncthreads();
-        for (int idx = tid; idx < m * Kb; idx += NT) {
-          const int j = idx / Kb, k = idx - j * Kb;
-          double acc = Tt[j * P + k];
-          for (int i = 0; i < sr; ++i) acc += Vp[(r0 + i) * m + j] * stage[i * Kb + k];
-          Tt[j * P + k] = acc;
-        }
-        __syncthreads();
-      }
-      for (int idx = tid; idx < ma * m; idx += NT) KV[oa * m + idx] = Vp[idx];
-      __syncthreads();
-    }
-    // hv = H w_pa  (wave per row)
-    {
-      const int lane = tid & 63, wid = tid >> 6;
-      for (int j = wid; j < m; j += NT / 64) {
-        double acc = 0.0;
-        for (int k = lane; k < P; k += 64) acc += Tt[j * P + k] * wv[k];
-        acc = wave_sum(acc);
-        if (lane == 0) hv[j] = acc;
-      }
-    }
-    __syncthreads();
-
-    if (MODE == MODE_PREDICT) {
-      // spamtree_model.cpp:1306-1326: w_i = H_i w_pa + sqrt(max(K_ii - H_i K_{pa,i}, 0)) z_i
-      for (int i = tid; i < m; i += NT) {
-        double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
-        for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + i];
-        const double sd = (acc > 0.0) ? sqrt(acc) : 0.0;
-        A.w_out[B.row0 + i] = hv[i] + sd * A.z[B.row0 + i];
-      }
-      continue;
-    }
-
-    double *pu = A.panels + B.panel_off;
-    const int ld = B.ld;
-    double wcore_part = 0.0, logdet_part = 0.0;
-    if (B.isref) {
-      // R = K_uu - V'V  (lower), chol, inverse
-      for (int idx = tid; idx < m * m; idx += NT) {
-        const int i = idx / m, j = idx - i * m;
-        if (j <= i) {
-          double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]);
-          for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + j];
-          R[idx] = acc;
-        } else {
-          R[idx] = 0.0;
-        }
-      }
-      chol_lower_inplace(R, m, &s_fail);
-      tri_inverse_lower(R, Ri, m);
-      // panel_u = [ -Ri*T | Ri ]
-      for (int idx = tid; idx < m * P; idx += NT) {
-        const int i = idx / P, k = idx - i * P;
-        double acc = 0.0;
-        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * Tt[j * P + k];
-        pu[(size_t)i * ld + k] = -acc;
-      }
-      for (int idx = tid; idx < m * m; idx += NT) {
-        const int i = idx / m, j = idx - i * m;
-        pu[(size_t)i * ld + P + j] = Ri[idx];
-      }
-      // e = Ri (w_u - H w_pa)
-      for (int i = tid; i < m; i += NT) {
-        double acc = 0.0;
-        for (int j = 0; j <= i; ++j) acc += Ri[i * m + j] * (wv[P + j] - hv[j]);
-        wcore_part += acc * acc;
-        logdet_part += log(Ri[i * m + i]);
-      }
-    } else {
-      // non-reference level: rows conditionally independent (spamtree_model.cpp:923-963)
-      for (int i = tid; i < m; i += NT) {
-        double acc = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + i], sy[P + i], smv[P + i]);
-        for (int k = 0; k < P; ++k) acc -= KV[k * m + i] * KV[k * m + i];
-        if (!(acc > 0.0)) s_fail = 1;
-        const double r = 1.0 / sqrt(acc);
-        rd[i] = r;
-        pu[(size_t)i * ld + P] = r;
-        const double e = r * (wv[P + i] - hv[i]);
-        wcore_part += e * e;
-        logdet_part += log(r);
-      }
-      __syncthreads();
-      for (int idx = tid; idx < m * P; idx += NT) {
-        const int i = idx / P, k = idx - i * P;
-        pu[(size_t)i * ld + k] = -rd[i] * Tt[idx];
-      }
-    }
-    const double wcore = block_sum(wcore_part, s_red);
-    const double logdet = block_sum(logdet_part, s_red);
-    __syncthreads();
-    if (tid == 0) {
-      A.logdet_c[b] = logdet;
-      A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
-      if (s_fail) atomicMin(A.errflag, B.level * 16 + (J == 0 ? 1 : (B.isref ? 2 : 3)));
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase A, fast path: one workgroup (4 waves) per COLUMN GROUP = one reference block, or several sibling
-// non-reference blocks (same ancestor chain), M <= 32 columns, chain P <= 256.  All dense contractions run on the
-// FP64 matrix cores (v_mfma_f64_16x16x4_f64: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], C[(l>>4)+4r][l&15]):
-//   per ancestor panel (last to first), in sub-panels of <= 16 rows staged in LDS:
-//     V_sub = Linv_sub * K[0:Kb, :]          16 x 32 tile pair, K split over the two wave pairs
-//     T^T[0:Kb, :] += Linv_sub^T * V_sub      accumulators stay in registers (<= 8 tiles of 16x16 per wave);
-//                                             the V tile in C layout IS the B operand of this product
-//   epilogue: R = K_uu - V'V (MFMA), Cholesky + inverse in LDS, panel_u = [-Ri*T | Ri] (MFMA), log-density terms.
-// K/V live in LDS as KV[k][ldKV]; T^T is dumped into the same buffer for the epilogue.
-// ---------------------------------------------------------------------------------------------------------------
-
-// 64-bit v_readlane (the lane index must be wave-uniform)
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
-
-#define CH_LD 33
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-// Team elimination [A | I] -> [. | L^{-1}] of an m x m SPD matrix (m <= 32): the workgroup is split into teams of TEAM
-// threads (128, or the whole workgroup), one matrix each; all teams run the same pivot loop (mmax = largest m, uniform) and share its barrier.
-// Every thread keeps EPT elements of the lower triangles of A and of B = I in registers (m (m + 1) <= TEAM * EPT).
-// Per pivot k the team publishes, UNSCALED, column k of A strictly below the diagonal, the pivot d_k itself, and row k
-// of B; everything outside those ranges reads as zero, so the update is the same two instructions for every element
-// at every pivot -- val -= (x1 x2) / d_k with x1 = A[i][k], x2 = A[j][k] or B[k][j] -- with no range tests; rows are
-// scaled by 1 / sqrt(d_i) once at the end.
-//   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).
-//   pub: 224 doubles per team: 2 x 96 published cells ([0,36) column, [36,72) row, [80] pivot, [95] always zero), rsd[32]
-typedef __attribute__((address_space(3))) double q_lds_double;
-template <int EPT, int TEAM = 128>
-__device__ __forceinline__ void team_chol_eliminate(double *Am, double *Bm, int m, int mmax, double *pub, int *fail, int ttid) {
-  const int nA = m * (m + 1) / 2, nE = 2 * nA;
-  double *rsd = pub + 192;
-  for (int i = ttid; i < 192; i += TEAM) pub[i] = 0.0;
-  lds_barrier();   // Am was written by other threads; pub is zero
-  // per element: 32-bit LDS addresses of its two factors and of its publication cell in buffer 0 (buffer 1 = +96
-  // doubles, an immediate offset in the unrolled pivot pair below), the pivot at which it is published, its output slot
-  q_lds_double *p1[EPT], *p2[EPT], *pp[EPT];
-  int khi[EPT], eoff[EPT];
-  double val[EPT];
-  q_lds_double *pub3 = (q_lds_double *)pub;
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) {
-    const int e = ttid + TEAM * r;
-    p1[r] = pub3 + 95; p2[r] = pub3 + 95; pp[r] = pub3 + 94; khi[r] = -1; eoff[r] = -1; val[r] = 0.0;
-    if (e < nE) {
-      const int t = e < nA ? 0 : 1;
-      const int f = e - t * nA;
-      int i = (int)((sqrtf(8.0f * (float)f + 1.0f) - 1.0f) * 0.5f);
-      while (i * (i + 1) / 2 > f) --i;
-      while ((i + 1) * (i + 2) / 2 <= f) ++i;
-      const int j = f - i * (i + 1) / 2;
-      p1[r] = pub3 + i;
-      p2[r] = pub3 + (t == 0 ? j : 36 + j);
-      pp[r] = pub3 + (t == 0 ? (i == j ? 80 : i) : 36 + j);
-      khi[r] = t == 0 ? j : i;
-      eoff[r] = t == 1 ? i * CH_LD + j : -1;
-      val[r] = t == 0 ? Am[i * CH_LD + j] : (i == j ? 1.0 : 0.0);
-    }
-  }
-#define TCH_PIVOT(k_, PAR)                                                                                     \
-  {                                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < EPT; ++r) if ((k_) == khi[r]) pp[r][(PAR) * 96] = val[r];            \
-    if (ttid == 0) { pub3[(PAR) * 96 + (k_)] = 0.0; if ((k_) > 0) pub3[(PAR) * 96 + (k_) - 1] = 0.0; }          \
-    lds_barrier();                                                                                             \
-    if ((k_) < m) {                                                                                            \
-      const double d = pub3[(PAR) * 96 + 80];                                                                  \
-      if (ttid == 0) { if (!(d > 0.0)) *fail = 1; rsd[(k_)] = rsqrt(d); }                                      \
-      double rd = __builtin_amdgcn_rcp(d);                                                                     \
-      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
-      rd = fma(fma(-d, rd, 1.0), rd, rd);                                                                      \
-      _Pragma("unroll") for (int r = 0; r < EPT; ++r) {                                                        \
-        const double x1 = p1[r][(PAR) * 96], x2 = p2[r][(PAR) * 96];                                           \
-        val[r] = fma(-(x1 * x2), rd, val[r]);                                                                  \
-      }                                                                                                        \
-    }                                                                                                          \
-  }
-  for (int k = 0; k < mmax; k += 2) {
-    TCH_PIVOT(k, 0)
-    if (k + 1 < mmax) TCH_PIVOT(k + 1, 1)
-  }
-#undef TCH_PIVOT
-  lds_barrier();   // rsd complete
-#pragma unroll
-  for (int r = 0; r < EPT; ++r)
-    if (eoff[r] >= 0) Bm[eoff[r]] = val[r] * rsd[khi[r]];
-  lds_barrier();
-}
-
-
-// The same elimination by ONE wave, without LDS traffic or barriers: lane i keeps row i of A (lower triangle) and of
-// B = I in registers; per pivot the pivot, column k of A (lane j's a[k]) and row k of B (lane k's b[j]) travel through
-// v_readlane (wave-uniform SGPR operands of the updates).  Fully unrolled (static register indices): MM pivots of MM
-// broadcasts + MM fused multiply-adds, about 400 cycles per pivot on an otherwise idle SIMD -- the team version's pivot
-// costs a workgroup barrier round trip (about 1.4k cycles with eight waves).  m <= MM <= 32; rows >= m behave as identity.
-//   Am: LDS, row stride CH_LD, lower triangle valid.   Bm: receives L^{-1} (lower triangle).  All 64 lanes must call.
-__device__ __forceinline__ double wave_allsum(double x);
-// The block-Gibbs draw w = L^{-T} (L^{-1} b + z), S = L L' (spamtree_model.cpp:1054, 1086: Sigi_chol = L^{-1},
-// w = Sigi_chol' (Sigi_chol Smu + z)), by ONE wave without ever forming L^{-1}: lane i keeps row i of S in registers;
-// the right-hand side rides along the elimination as one more column (forward substitution for free); the backward
-// substitution costs one wave sum per row.  No LDS traffic, no barriers inside.  m <= MM <= 32.  All 64 lanes must call.
-//   Sm: LDS, row stride CH_LD, lower triangle valid.  bm, zm, wout: LDS vectors (wout may alias bm or zm).
-// core: lane i holds row i of S in a[] (entries j <= i; the caller sets a[j] = (j == lane) for rows >= m and 0 above the
-// diagonal), c = b_i, zi = z_i; returns w_i (lanes >= m: unspecified)
-template <int MM>
-__device__ __forceinline__ double wave_chol_solve_core(double (&a)[MM], double c, const double zi, int m, int *fail, int lane) {
-  double dd = 1.0;
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < MM; ++k) {
-    if (k < m) {   // wave-uniform
-      const double d = readlane_f64(a[k], k);
-      bad = bad || !(d > 0.0);
-      dd = lane == k ? d : dd;
-      double rd = __builtin_amdgcn_rcp(d);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      const double f = lane > k ? -a[k] * rd : 0.0;
-#pragma unroll
-      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
-      c = fma(f, readlane_f64(c, k), c);
-    }
-  }
-  if (bad && lane == 0) *fail = 1;
-  // a[k] of lane i > k is now L_ik L_kk, the diagonal d_i = L_ii^2, c = L_ii y_i
-  const double rs = rsqrt(dd);
-  const double t = fma(c, rs, zi);      // y_i + z_i
-  double w = 0.0;
-#pragma unroll
-  for (int k = MM - 1; k >= 0; --k) {
-    if (k < m) {   // wave-uniform
-      const double sk = wave_allsum(lane > k ? a[k] * w : 0.0);          // sum_{i > k} L_ik L_kk w_i
-      const double rk = readlane_f64(rs, k);
-      const double wk = (readlane_f64(t, k) - rk * sk) * rk;
-      w = lane == k ? wk : w;
-    }
-  }
-  return w;
-}
-template <int MM>
-__device__ __forceinline__ void wave_chol_solve(const double *Sm, const double *bm, const double *zm, double *wout, int m, int *fail, int lane) {
-  double a[MM];
-  const bool row = lane < m;
-#pragma unroll
-  for (int j = 0; j < MM; ++j) a[j] = (row && j <= lane) ? Sm[min(lane, 31) * CH_LD + j] : (j == lane ? 1.0 : 0.0);
-  const double c = row ? bm[min(lane, 31)] : 0.0;   // running right-hand side: ends as L_ii y_i
-  const double zi = row ? zm[min(lane, 31)] : 0.0;
-  const double w = wave_chol_solve_core<MM>(a, c, zi, m, fail, lane);
-  if (row) wout[lane] = w;
-}
-
-template <int MM, int J0 = 0, int J1 = MM>
-__device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm, int m, int *fail, int lane) {
-  // J0, J1: this wave produces columns [J0, J1) of L^{-1}.  Two waves can share one matrix: both run the (cheaper half of
-  // the) elimination of A redundantly -- no communication -- and each carries half of B's columns.
-  double a[MM], b[MM];
-  const bool row = lane < m;
-#pragma unroll
-  for (int j = 0; j < MM; ++j) {
-    a[j] = (row && j <= lane) ? Am[min(lane, 31) * CH_LD + j] : (j == lane ? 1.0 : 0.0);
-    b[j] = j == lane ? 1.0 : 0.0;
-  }
-  double dd = 1.0;
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < MM; ++k) {
-    if (k < m) {   // wave-uniform
-      const double d = readlane_f64(a[k], k);
-      bad = bad || !(d > 0.0);
-      dd = lane == k ? d : dd;
-      double rd = __builtin_amdgcn_rcp(d);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      const double f = lane > k ? -a[k] * rd : 0.0;
-#pragma unroll
-      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
-#pragma unroll
-      for (int j = J0; j < J1; ++j)
-        if (j <= k) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
-    }
-  }
-  if (bad && lane == 0) *fail = 1;
-  const double rs = rsqrt(dd);
-  if (row) {
-#pragma unroll
-    for (int j = J0; j < J1; ++j)
-      if (j <= lane) Bm[lane * CH_LD + j] = b[j] * rs;
-  }
-}
-
-
-// wave_chol_eliminate for a 16 x 16 (or smaller) diagonal tile that sits inside a larger matrix: strides as parameters.
-//   Am: tile's first element, row stride lda, lower triangle valid.  Bm: receives L^{-1} (lower triangle), row stride ldb.
-//   mr <= 16 rows; rows >= mr behave as identity and are not written.  All 64 lanes must call.
-__device__ __forceinline__ void wave_chol_eliminate_tile(const double *Am, int lda, double *Bm, int ldb, int mr, int *fail, int lane) {
-  constexpr int MM = 16;
-  double a[MM], b[MM];
-  const bool row = lane < mr;
-  const int lr = min(lane, MM - 1);
-#pragma unroll
-  for (int j = 0; j < MM; ++j) {
-    a[j] = (row && j <= lane) ? Am[(size_t)lr * lda + j] : (j == lane ? 1.0 : 0.0);
-    b[j] = j == lane ? 1.0 : 0.0;
-  }
-  double dd = 1.0;
-  bool bad = false;
-#pragma unroll
-  for (int k = 0; k < MM; ++k) {
-    if (k < mr) {   // wave-uniform
-      const double d = readlane_f64(a[k], k);
-      bad = bad || !(d > 0.0);
-      dd = lane == k ? d : dd;
-      double rd = __builtin_amdgcn_rcp(d);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      rd = fma(fma(-d, rd, 1.0), rd, rd);
-      const double f = lane > k ? -a[k] * rd : 0.0;
-#pragma unroll
-      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
-#pragma unroll
-      for (int j = 0; j < MM; ++j)
-        if (j <= k) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
-    }
-  }
-  if (bad && lane == 0) *fail = 1;
-  const double rs = rsqrt(dd);
-  if (row) {
-#pragma unroll
-    for (int j = 0; j < MM; ++j)
-      if (j <= lane) Bm[(size_t)lane * ldb + j] = b[j] * rs;
-  }
-}
-
-// Ri = chol(A)^{-1} (same contract as block_chol_invert: m x m in LDS, row stride m, lower triangle of A valid, A destroyed,
-// *fail set when a pivot is not > 0, all threads must call, Ri must not alias A) as a BLOCKED factorisation on 16 x 16 tiles:
-// per block column, the diagonal tile's inverse Cholesky factor X_kk by one wave in registers (wave_chol_eliminate_tile), the
-// panel L_ik = A_ik X_kk' and the trailing update A_ij -= L_ik L_jk' on the FP64 matrix cores (tiles dealt over the waves);
-// then the inverse by block sub-diagonals, Ri_ij = -X_ii sum_k L_ik Ri_kj.  3 barriers per block column + 1 per sub-diagonal:
-// 19 for a 75 x 75 matrix, against one per PIVOT (75) of block_chol_invert, whose 8-wave barrier round trips were 23 % of a
-// 75-column reference level of config #4.  Entries above the diagonal of Ri are zero.
-// the factorisation half of block_chol_invert_mfma: on return A (row stride lda) holds L_ik in its tiles below the block
-// diagonal and X (row stride ldx; may be A itself: X_kk then replaces the lower triangle of A's diagonal tile) holds
-// X_kk = L_kk^{-1} in the lower triangles of its diagonal tiles.  All threads of the block must call.
-__device__ __forceinline__ void block_chol_factor_mfma(double *A, int lda, double *X, int ldx, int m, int *fail) {
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
-  const int nt = (m + 15) >> 4;
-  auto la = [&](int r, int c) -> double { return (r < m && c < m) ? A[(size_t)r * lda + c] : 0.0; };
-  for (int kb = 0; kb < nt; ++kb) {
-    const int k0 = 16 * kb;
-    if (wid == 0) wave_chol_eliminate_tile(A + (size_t)k0 * lda + k0, lda, X + (size_t)k0 * ldx + k0, ldx, min(16, m - k0), fail, lane);
-    __syncthreads();
-    // panel: L_ik = A_ik X_kk'  (B operand: X_kk'[k][n] = X_kk[n][k], lower triangular)
-    for (int ib = kb + 1 + wid; ib < nt; ib += nw) {
-      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-        const int xr = k0 + l15, xc = k0 + 4 * s2 + l4;
-        const double xb = (xr < m && xc <= xr) ? X[(size_t)xr * ldx + xc] : 0.0;
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(la(16 * ib + l15, k0 + 4 * s2 + l4), xb, c, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 16 * ib + 4 * q + l4, cc = k0 + l15;
-        if (r < m && cc < m) A[(size_t)r * lda + cc] = c[q];
-      }
-    }
-    __syncthreads();
-    // trailing update: A_ij -= L_ik L_jk' for kb < jb <= ib
-    {
-      const int nr = nt - kb - 1, npair = nr * (nr + 1) / 2;
-      for (int e = wid; e < npair; e += nw) {
-        int ii = 0;
-        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-        const int jj = e - ii * (ii + 1) / 2;
-        const int ib = kb + 1 + ii, jb = kb + 1 + jj;
-        d4 c;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) c[q] = la(16 * ib + 4 * q + l4, 16 * jb + l15);
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(-la(16 * ib + l15, k0 + 4 * s2 + l4), la(16 * jb + l15, k0 + 4 * s2 + l4), c, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = 16 * ib + 4 * q + l4, cc = 16 * jb + l15;
-          if (r < m && cc < m) A[(size_t)r * lda + cc] = c[q];
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-__device__ void block_chol_invert_mfma(double *A, double *Ri, int m, int *fail) {
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
-  const int nt = (m + 15) >> 4;
-  for (int idx = tid; idx < m * m; idx += blockDim.x) Ri[idx] = 0.0;
-  __syncthreads();
-  auto ld = [&](const double *M_, int r, int c) -> double { return (r < m && c < m) ? M_[(size_t)r * m + c] : 0.0; };
-  block_chol_factor_mfma(A, m, Ri, m, m, fail);
-  // A now holds L_ik below the block diagonal, Ri's diagonal tiles X_kk.  Ri_ij = -X_ii sum_{k = j}^{i-1} L_ik Ri_kj
-  for (int d = 1; d < nt; ++d) {
-    for (int jb = wid; jb + d < nt; jb += nw) {
-      const int ib = jb + d;
-      d4 w = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int kb = jb; kb < ib; ++kb) {
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-          w = __builtin_amdgcn_mfma_f64_16x16x4f64(ld(A, 16 * ib + l15, 16 * kb + 4 * s2 + l4), ld(Ri, 16 * kb + 4 * s2 + l4, 16 * jb + l15), w, 0, 0, 0);
-      }
-      d4 r4 = (d4){0.0, 0.0, 0.0, 0.0};   // the accumulator layout of W is the B-operand layout of its four K-steps
-#pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2)
-        r4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ld(Ri, 16 * ib + l15, 16 * ib + 4 * s2 + l4), w[s2], r4, 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = 16 * ib + 4 * q + l4, cc = 16 * jb + l15;
-        if (r < m && cc < m) Ri[(size_t)r * m + cc] = r4[q];
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
-// w = L^{-T} (L^{-1} b + z), S = L L' (m x m in LDS, row stride lds_, lower triangle valid, destroyed), for 33..80-row blocks, by
-// the whole workgroup: the blocked factorisation above with X_kk stored over S's own diagonal tiles, then block forward and
-// backward substitutions -- thread i owns row i; a block step is one 16 x 16 triangular product with X_kk (through `vec`, m
-// doubles of LDS) and one rank-16 update of the rows below / above.  About 35 barriers of four waves and five one-wave 16 x 16
-// eliminations, against the 75 dependent pivots of wave_chol_solve_lds.  bv (LDS): in b, out w.  All threads must call.
-__device__ void block_chol_solve_mfma(double *S, int lds_, double *vec, double *bv, const double *zg, int m, int *fail) {
-  const int tid = threadIdx.x;
-  const int nt = (m + 15) >> 4;
-  block_chol_factor_mfma(S, lds_, S, lds_, m, fail);
-  const int i = tid, ib = tid >> 4;           // row i (tid < m)
-  const bool rowok = i < m;
-  double r = rowok ? bv[i] : 0.0;
-  for (int kb = 0; kb < nt; ++kb) {           // forward: y_k = X_kk r_k, then r_i -= L_ik y_k for the rows below
-    const int k0 = 16 * kb, k1 = min(m, k0 + 16);
-    if (rowok && ib == kb) vec[i] = r;
-    __syncthreads();
-    double y = 0.0;
-    if (rowok && ib == kb) {
-      for (int c = k0; c <= i; ++c) y += S[(size_t)i * lds_ + c] * vec[c];
-    }
-    __syncthreads();
-    if (rowok && ib == kb) { vec[i] = y; r = y; }
-    __syncthreads();
-    if (rowok && ib > kb) {
-      for (int c = k0; c < k1; ++c) r -= S[(size_t)i * lds_ + c] * vec[c];
-    }
-  }
-  double t = rowok ? r + zg[i] : 0.0;         // r = y = L^{-1} b
-  for (int kb = nt - 1; kb >= 0; --kb) {      // backward: w_k = X_kk' t_k, then t_i -= L_ki' w_k for the rows above
-    const int k0 = 16 * kb, k1 = min(m, k0 + 16);
-    __syncthreads();
-    if (rowok && ib == kb) vec[i] = t;
-    __syncthreads();
-    double w = 0.0;
-    if (rowok && ib == kb) {
-      for (int c = i; c < k1; ++c) w += S[(size_t)c * lds_ + i] * vec[c];
-    }
-    __syncthreads();
-    if (rowok && ib == kb) { vec[i] = w; t = w; }
-    __syncthreads();
-    if (rowok && ib < kb) {
-      for (int c = k0; c < k1; ++c) t -= S[(size_t)c * lds_ + i] * vec[c];
-    }
-  }
-  if (rowok) bv[i] = t;
-  __syncthreads();
-}
-
-#ifdef FM_STAMPS
-// diagnostic build only (never shipped): per-section shader-clock totals of k_factor_mfma, thread 0 of every workgroup
-__device__ unsigned long long g_stamps[16];
-#define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_t0 = clock64(), st_t1 = 0;
-#define STAMP(slot) do { st_t1 = clock64(); st_acc[slot] += st_t1 - st_t0; st_t0 = st_t1; } while (0)
-__device__ int g_stamp_level = -1;   // >= 0: only workgroups of that tree level report (k_factor_quad)
-#define STAMP_FLUSH_IF(c_) do { if (threadIdx.x == 0 && (c_)) { for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&g_stamps[q_], st_acc[q_]); } } while (0)
-#define STAMP_FLUSH STAMP_FLUSH_IF(g_stamp_level < 0)
-#define STAMP_FLUSH_LEVEL(l_) STAMP_FLUSH_IF(g_stamp_level < 0 || g_stamp_level == (l_))
-extern "C" int st_debug_stamp_level(int level) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_level), &level, sizeof(int)); return 0; }
-extern "C" int st_debug_stamps(unsigned long long *out, int reset) {
-  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
-  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
-  return 0;
-}
-#else
-#define STAMP_DECL
-#define STAMP(slot) do {} while (0)
-#define STAMP_FLUSH do {} while (0)
-#define STAMP_FLUSH_LEVEL(l_) do {} while (0)
-#endif
-
-
-struct Grp {
-  long long row0;  // first device row of the group's columns
-  int blk0, nblk;  // device blocks blk0 .. blk0+nblk-1 (siblings)
-  int M, P;
-};
-
-// Group descriptor: everything the per-group kernels used to chase through grps -> blks -> anc_idx -> blks -> dch_idx ->
-// blks, flattened on the host into one fixed-stride record of 64-bit words (one global round trip instead of four):
-//   [0] row0  [1] acc_off  [2] M | P<<32  [3] J | nblk<<32  [4] isref | level<<32  [5] nch | acc_len<<32  [6] blk0
-//   [7] total record length   then per ancestor t: am | ao<<32, first row, panel offset, record offset (4 words)
-//   then per block: panel offset, first row, ld (3 words)   then per direct child holding a record: its acc_off
-#define GD_MAXW 272
-struct GdHead {
-  long long row0, acc_off;
-  int M, P, nanc, nblk, isref, level, ndch, acc_len, blk0;
-};
-__device__ __forceinline__ GdHead gd_unpack(const long long *s_gd, int tid, int *s_am, int *s_ao, long long *s_arow, long long *s_apan,
-                                            long long *s_aoff, long long *s_bpan, long long *s_brow, int *s_bld, long long *s_coff) {
-  GdHead H;
-  // every thread reads the same words: keep the header in scalar registers
-  auto sll = [](long long v) {
-    const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)), hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-    return ((long long)hi << 32) | (unsigned int)lo;
-  };
-  auto slo = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)); };
-  auto shi = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v >> 32)); };
-  H.row0 = sll(s_gd[0]); H.acc_off = sll(s_gd[1]);
-  H.M = slo(s_gd[2]); H.P = shi(s_gd[2]);
-  H.nanc = slo(s_gd[3]); H.nblk = shi(s_gd[3]);
-  H.isref = slo(s_gd[4]); H.level = shi(s_gd[4]);
-  H.ndch = slo(s_gd[5]); H.acc_len = shi(s_gd[5]);
-  H.blk0 = slo(s_gd[6]);
-  if (tid < H.nanc) {
-    const long long *a = s_gd + 8 + 4 * tid;
-    s_am[tid] = (int)(a[0] & 0xffffffffLL); s_ao[tid] = (int)(a[0] >> 32);
-    s_arow[tid] = a[1];
-    if (s_apan) s_apan[tid] = a[2];
-    if (s_aoff) s_aoff[tid] = a[3];
-  }
-  if (tid == 0) { s_ao[H.nanc] = H.P; if (s_aoff) s_aoff[H.nanc] = s_gd[7]; }
-  if (tid >= 64 && tid < 64 + H.nblk) {
-    const long long *b = s_gd + 8 + 4 * H.nanc + 3 * (tid - 64);
-    s_bpan[tid - 64] = b[0]; s_brow[tid - 64] = b[1]; s_bld[tid - 64] = (int)b[2];
-  }
-  if (s_coff && tid >= 128 && tid < 128 + H.ndch) s_coff[tid - 128] = s_gd[8 + 4 * H.nanc + 3 * H.nblk + (tid - 128)];
-  return H;
-}
-
-struct FastArgs {
-  const Blk *blks;
-  const int *anc_idx;
-  const Grp *grps;
-  int ngrp;
-  const double *cx, *cy;
-  const int *mv;
-  const double *w;
-  double *panels;
-  double *logdet_c, *loglik_c;
-  int *errflag;
-  const long long *gdesc;   // group descriptors of this launch's first group onwards
-  int gd_stride;
-  int Pm4, ldKV, ldS, SRm, stage_dbl;
-};
-
-#define FM_VPART 512
-
-__global__ __launch_bounds__(NT, 2) void k_factor_mfma(FastArgs A, CovPar cp) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
-  __shared__ int s_fail;
-  __shared__ double s_red[NT / 64];
-  __shared__ long long s_bpan[32], s_brow[32];   // panel offset / first row of the group's blocks
-  __shared__ int s_bld[32];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int jt = wid & 1, kh = wid >> 1;
-  const int Pm4 = A.Pm4, ldKV = A.ldKV, ldS = A.ldS, SRm = A.SRm;
-  double *KV = lds;
-  double *stage = KV + (size_t)Pm4 * ldKV + 16;
-  double *Vpart = stage + A.stage_dbl;
-  double *zrow = Vpart - (ldS + 16);   // a row of zeros at the end of the stage area (never overwritten)
-  double *colx = Vpart + FM_VPART, *coly = colx + 32, *colw = coly + 32, *hv = colw + 32, *rd = hv + 32;
-  int *colmv = (int *)(rd + 32);
-  int *colblk = colmv + 32;
-
-  STAMP_DECL
-  // workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous run of
-  // groups so that siblings, which stream the same ancestor panels, meet in one L2
-  int gidx = blockIdx.x;
-  {
-    const int per = A.ngrp >> 3;
-    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-  }
-  long long *s_gd = (long long *)stage;   // the group's descriptor lands in the (still unused) stage area: one round trip
-  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
-  __syncthreads();
-  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, s_apan, nullptr, s_bpan, s_brow, s_bld, nullptr);
-  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
-  const int M = G.M, P = G.P, J = B0.nanc;
-  const long long b0_panel_off = s_gd[8 + 4 * J];
-  const int b0_ld = (int)s_gd[8 + 4 * J + 2];
-  if (tid == 0) s_fail = 0;
-  __syncthreads();
-  // ---- prologue: coordinates (ancestors alias the stage area), K_{pa,u} into KV, pads zeroed
-  {
-    double *sx = stage, *sy = stage + Pm4;
-    int *smv = (int *)(stage + 2 * (size_t)Pm4);
-    for (int t = 0; t < J; ++t) {
-      const long long r0 = s_arow[t];
-      const int oa = s_ao[t];
-      for (int i = tid; i < s_am[t]; i += NT) { sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; }
-    }
-    if (tid < 32) {
-      const int j = tid;
-      if (j < M) {
-        const long long r = G.row0 + j;
-        colx[j] = A.cx[r]; coly[j] = A.cy[r]; colw[j] = A.w[r]; colmv[j] = A.mv[r];
-        int bi = 0;
-        while (bi + 1 < G.nblk && r >= s_brow[bi + 1]) ++bi;
-        colblk[j] = bi;
-      } else {
-        colx[j] = 0.0; coly[j] = 0.0; colw[j] = 0.0; colmv[j] = 0; colblk[j] = 0;
-      }
-    }
-    for (int k = tid; k < ldS + 16; k += NT) zrow[k] = 0.0;
-    __syncthreads();
-    const float invld = 1.0f / (float)ldKV;
-    for (int idx = tid; idx < Pm4 * ldKV + 16; idx += NT) {
-      const int k = (int)(((float)idx + 0.5f) * invld), j = idx - k * ldKV;   // exact: idx < 2^14, ldKV <= 32
-      KV[idx] = (k < P && j < M) ? cov_entry(cp, sx[k], sy[k], smv[k], colx[j], coly[j], colmv[j]) : 0.0;
-    }
-  }
-  d4 acc[8];
-#pragma unroll
-  for (int n = 0; n < 8; ++n) acc[n] = (d4){0.0, 0.0, 0.0, 0.0};
-  STAMP(0);
-
-  // ---- one pass over the ancestor chain, last ancestor first, in sub-panels of <= 16 rows.  The next
-  // sub-panel is fetched from global memory into registers while the matrix cores work on the current one.
-  {
-    double pre[16];   // rows wid, wid+4, wid+8, wid+12 of the sub-panel x 4 chunks of 64 columns
-    auto sub_geom = [&](int t, int s, int &r0, int &sr, int &Kb) {
-      const int ma = s_am[t];
-      const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
-      r0 = s == 0 ? 0 : sr0;
-      sr = s == 0 ? sr0 : ma - sr0;
-      Kb = s_ao[t] + ma;
-    };
-    auto fetch = [&](int t, int s) {
-      int r0, sr, Kb;
-      sub_geom(t, s, r0, sr, Kb);
-      const double *src = A.panels + s_apan[t] + (size_t)(r0 + wid) * Kb + lane;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-#ifdef FM_NOFETCH
-          pre[rr * 4 + c] = 1e-3;
-#else
-          pre[rr * 4 + c] = (wid + 4 * rr < sr && lane + 64 * c < Kb) ? src[(size_t)(4 * rr) * Kb + 64 * c] : 0.0;
-#endif
-        }
-      }
-    };
-    int t = J - 1, s = 0;
-    if (t >= 0) fetch(t, s);
-    d4 vt0 = (d4){0.0, 0.0, 0.0, 0.0}, vt1 = vt0;
-    while (t >= 0) {
-      const int ma = s_am[t], oa = s_ao[t];
-      const int nsub = ma > 16 ? 2 : 1;
-      int r0, sr, Kb;
-      sub_geom(t, s, r0, sr, Kb);
-      __syncthreads();  // everyone is done with the previous contents of `stage` (and with the prologue alias)
-      STAMP(1);
-      {
-        double *dst = stage + (size_t)wid * ldS + lane;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (wid + 4 * rr < sr && lane + 64 * c < Kb) dst[(size_t)(4 * rr) * ldS + 64 * c] = pre[rr * 4 + c];
-        }
-        if (tid < sr * 4) stage[(size_t)(tid >> 2) * ldS + Kb + (tid & 3)] = 0.0;   // k in [Kb, Kb+4) reads as zero
-      }
-      int tn = t, sn = s + 1;
-      if (sn >= nsub) { tn = t - 1; sn = 0; }
-      if (tn >= 0) fetch(tn, sn);
-      __syncthreads();
-      STAMP(2);
-      // V_sub partial over this wave pair's half of K.  Rows >= sr read the zero row, columns in [Kb, Kb+4)
-      // were zero-filled, so the loop body is two LDS reads and one MFMA.
-      const int ns = (Kb + 3) >> 2, nh = (ns + 1) >> 1;
-      const int st0 = kh ? nh : 0, st1 = kh ? ns : nh;
-      d4 p = (d4){0.0, 0.0, 0.0, 0.0};
-      {
-        const double *ap = ((l15 < sr) ? stage + (size_t)l15 * ldS : zrow) + 4 * st0 + l4;
-        const double *bp = KV + (size_t)(4 * st0 + l4) * ldKV + jt * 16 + l15;
-        const int bstep = 4 * ldKV;
-        int st = st0;
-        for (; st + 4 <= st1; st += 4) {
-          const double a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-          const double b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
-          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p, 0, 0, 0);
-          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p, 0, 0, 0);
-          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, p, 0, 0, 0);
-          p = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, p, 0, 0, 0);
-          ap += 16; bp += 4 * bstep;
-        }
-        for (; st < st1; ++st) {
-          p = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], p, 0, 0, 0);
-          ap += 4; bp += bstep;
-        }
-      }
-      STAMP(3);
-      if (kh == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Vpart[jt * 256 + r * 64 + lane] = p[r];
-      }
-      __syncthreads();
-      if (kh == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[r] += Vpart[jt * 256 + r * 64 + lane];
-          Vpart[jt * 256 + r * 64 + lane] = p[r];
-        }
-      }
-      __syncthreads();
-      if (kh == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = Vpart[jt * 256 + r * 64 + lane];
-      }
-      if (s == 0) vt0 = p; else vt1 = p;
-      STAMP(4);
-      // T^T tiles (kt = kh, kh+2, ...) += Linv_sub^T * V_sub ; the V tile (C layout) is the B operand.
-      {
-        const int nst = (sr + 3) >> 2;
-        const int kb0 = kh * 16 + l15;
-        const double *r0p = ((l4 < sr) ? stage + (size_t)l4 * ldS : zrow) + kb0;
-        const double *r1p = ((4 + l4 < sr) ? stage + (size_t)(4 + l4) * ldS : zrow) + kb0;
-        const double *r2p = ((8 + l4 < sr) ? stage + (size_t)(8 + l4) * ldS : zrow) + kb0;
-        const double *r3p = ((12 + l4 < sr) ? stage + (size_t)(12 + l4) * ldS : zrow) + kb0;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const int kt = kh + 2 * n;
-          if (kt * 16 < Kb) {
-            const bool kok = kb0 + 32 * n < Kb;   // the boundary tile must not touch T columns of later panels
-            double a0 = r0p[32 * n], a1 = r1p[32 * n], a2 = r2p[32 * n], a3 = r3p[32 * n];
-            a0 = kok ? a0 : 0.0; a1 = kok ? a1 : 0.0; a2 = kok ? a2 : 0.0; a3 = kok ? a3 : 0.0;
-            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, p[0], acc[n], 0, 0, 0);
-            if (nst > 1) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, p[1], acc[n], 0, 0, 0);
-            if (nst > 2) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, p[2], acc[n], 0, 0, 0);
-            if (nst > 3) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, p[3], acc[n], 0, 0, 0);
-          }
-        }
-      }
-      // after the panel's last sub-panel its V rows replace the K rows they were computed from
-      // (later panels read only rows < oa)
-      if (s == nsub - 1 && kh == 0) {
-        const int sr0 = ma > 16 ? (ma + 1) >> 1 : ma;
-        const int j = jt * 16 + l15;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = l4 + 4 * r;
-          if (j < ldKV) {
-            if (i < sr0) KV[(size_t)(oa + i) * ldKV + j] = (nsub == 2) ? vt0[r] : p[r];
-            if (nsub == 2 && i < ma - sr0) KV[(size_t)(oa + sr0 + i) * ldKV + j] = vt1[r];
-          }
-        }
-      }
-      STAMP(5);
-      t = tn; s = sn;
-    }
-  }
-  __syncthreads();
-  STAMP(6);
-
-  const bool refgrp = B0.isref != 0;
-  double *R = stage, *Ri = stage + 32 * CH_LD;              // row stride CH_LD
-  double *chcol = Ri + 32 * CH_LD, *chrs = chcol + 216;       // elimination scratch: 2 x 3 x 36 published entries, pivots
-  if (refgrp) {
-    // ---- R = K_uu - V'V : wave -> tile (it, jt2)
-    const int it = wid >> 1, jt2 = wid & 1;
-    if (it * 16 < M && jt2 * 16 < M) {
-      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-      const double *ap = KV + (size_t)l4 * ldKV + it * 16 + l15;
-      const double *bp = KV + (size_t)l4 * ldKV + jt2 * 16 + l15;
-      const int stp = 4 * ldKV;
-      for (int st = 0; st < (Pm4 >> 2); ++st) {
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0], bp[0], c, 0, 0, 0);
-        ap += stp; bp += stp;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = it * 16 + l4 + 4 * r, j = jt2 * 16 + l15;
-        if (i < M && j < M)
-          R[i * CH_LD + j] = (j <= i) ? cov_entry(cp, colx[i], coly[i], colmv[i], colx[j], coly[j], colmv[j]) - c[r] : 0.0;
-      }
-    }
-    for (int idx = tid; idx < 32 * CH_LD; idx += NT) Ri[idx] = (idx / CH_LD == idx % CH_LD) ? 1.0 : 0.0;
-  } else {
-    if (tid < M) {
-      const int j = tid;
-      double d = cov_entry(cp, colx[j], coly[j], colmv[j], colx[j], coly[j], colmv[j]);
-      for (int k = 0; k < P; ++k) { const double v = KV[(size_t)k * ldKV + j]; d -= v * v; }
-      if (!(d > 0.0)) s_fail = 1;
-      rd[j] = 1.0 / sqrt(d);
-    }
-  }
-  __syncthreads();
-  STAMP(7);
-  // ---- dump T^T into the KV buffer (same [k][ldKV] layout); pads zero
-#pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    const int kt = kh + 2 * n;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = kt * 16 + l4 + 4 * r, j = jt * 16 + l15;
-      if (k < Pm4 && j < ldKV) KV[(size_t)k * ldKV + j] = (k < P && j < M) ? acc[n][r] : 0.0;
-    }
-  }
-  double *wpa = Vpart;  // P <= 256 <= FM_VPART
-  for (int t = 0; t < J; ++t)
-    for (int i = tid; i < s_am[t]; i += NT) wpa[s_ao[t] + i] = A.w[s_arow[t] + i];
-  __syncthreads();
-  // ---- Ri = chol(R)^{-1}: workgroup-wide elimination in LDS; then hv = T w_pa
-  if (refgrp) {   // element slots per thread: m (m + 1) <= 256 * slots
-    if (M <= 22) team_chol_eliminate<2, NT>(R, Ri, M, M, chcol, &s_fail, tid);
-    else if (M <= 27) team_chol_eliminate<3, NT>(R, Ri, M, M, chcol, &s_fail, tid);
-    else team_chol_eliminate<5, NT>(R, Ri, M, M, chcol, &s_fail, tid);
-  }
-  {
-    const int w0 = wid, nw = 4;
-    for (int j = w0; j < M; j += nw) {
-      double a = 0.0;
-      for (int k = lane; k < P; k += 64) a += KV[(size_t)k * ldKV + j] * wpa[k];
-      a = wave_sum(a);
-      if (lane == 0) hv[j] = a;
-    }
-  }
-  __syncthreads();
-
-  STAMP(8);
-  double wcore_part = 0.0, logdet_part = 0.0;
-  if (refgrp) {
-    double *pu = A.panels + b0_panel_off;
-    const int ld = b0_ld;
-    // ---- N = -Ri * T : tiles (it, kt), A[i][j] = -Ri[i][j] (lower), B[j][k] = T^T[k][j]
-    const int nkt = (P + 15) >> 4, nit = (M + 15) >> 4;
-    for (int tile = wid; tile < nit * nkt; tile += NT / 64) {
-      const int it = tile % nit, kt = tile / nit;
-      const int njs = (min(M, it * 16 + 16) + 3) >> 2;
-      const int i = it * 16 + l15;
-      const int krow = min(kt * 16 + l15, Pm4 - 1);
-      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int st = 0; st < njs; ++st) {
-        const int j = 4 * st + l4;
-        const double a = (i < M && j <= i) ? -Ri[i * CH_LD + j] : 0.0;
-        const double b = KV[(size_t)krow * ldKV + j];
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int io = it * 16 + l4 + 4 * r, k = kt * 16 + l15;
-        if (io < M && k < P) pu[(size_t)io * ld + k] = c[r];
-      }
-    }
-    for (int idx = tid; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      pu[(size_t)i * ld + P + j] = (j <= i) ? Ri[i * CH_LD + j] : 0.0;
-    }
-    if (tid < M) {
-      const int i = tid;
-      double e = 0.0;
-      for (int j = 0; j <= i; ++j) e += Ri[i * CH_LD + j] * (colw[j] - hv[j]);
-      wcore_part = e * e;
-      logdet_part = log(Ri[i * CH_LD + i]);
-    }
-    const double wcore = block_sum(wcore_part, s_red);
-    const double logdet = block_sum(logdet_part, s_red);
-    if (tid == 0) {
-      A.logdet_c[G.blk0] = logdet;
-      A.loglik_c[G.blk0] = (double)M * HL2PI - 0.5 * wcore;
-      if (s_fail) atomicMin(A.errflag, B0.level * 16 + (J == 0 ? 1 : 2));
-    }
-  } else {
-    // non-reference rows: panel row of column j = [ -r_j * T[j][:] | r_j ] in its own block
-    for (int j = wid; j < M; j += NT / 64) {   // one wave per column: coalesced row of the block's panel
-      const int bi = colblk[j];
-      double *prow = A.panels + s_bpan[bi] + (size_t)(G.row0 + j - s_brow[bi]) * s_bld[bi];
-      const double r = rd[j];
-      for (int k = lane; k < P; k += 64) prow[k] = -r * KV[(size_t)k * ldKV + j];
-      if (lane == 0) prow[P] = r;
-    }
-    if (tid < G.nblk) {
-      const int bi = tid;
-      double wc = 0.0, ldt = 0.0;
-      int cnt = 0;
-      for (int j = 0; j < M; ++j)
-        if (colblk[j] == bi) {
-          const double e = rd[j] * (colw[j] - hv[j]);
-          wc += e * e;
-          ldt += log(rd[j]);
-          ++cnt;
-        }
-      A.logdet_c[G.blk0 + bi] = ldt;
-      A.loglik_c[G.blk0 + bi] = (double)cnt * HL2PI - 0.5 * wc;
-    }
-    if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 3);
-  }
-  STAMP(9);
-  STAMP_FLUSH;
-}
-
-
+#include "st_device.hpp"
+#include "factor_generic.hpp"
+#include "factor_mfma.hpp"
 #include "chol_blocked.hpp"
 #include "factor_quad.hpp"
 #include "factor_big.hpp"
 #include "factor_wide.hpp"
 #include "factor_lchain.hpp"
-
-// w = L^{-T} (L^{-1} b + z), S = L L' (spamtree_model.cpp:1054, 1086), for blocks too wide for one wave's registers (75-row
-// blocks of the default multivariate tree), by ONE wave with S in LDS and NO workgroup barrier: the scratch-arena path pays
-// three __syncthreads() per pivot for the factorisation and four per row for the two substitutions (about a millisecond per
-// 75-row block, most of phase B at config #4).  Lane i owns rows i and i + 64 (m <= 128); right-looking elimination, the
-// scaled pivot column goes through `lcol` (m doubles of LDS) so that a batch of eight trailing columns costs four wide
-// uniform reads; the right-hand side rides along (forward substitution for free); the backward substitution walks L by rows.
-//   S: m x m (m <= 80), row stride ms (odd: conflict-free column walks; >= m + 7), lower triangle valid, destroyed.
-//   lcol: m + 8 doubles.  bv (LDS): in b, out w.
-//   zg: the block's normals (global).  All 64 lanes of the wave must call; nobody else may touch S, lcol, bv meanwhile.
-__device__ __forceinline__ void wave_chol_solve_lds(double *S, int ms, double *lcol, double *bv, const double *zg, int m, int *fail, int lane) {
-  // rows 0 .. 63: lane i owns row i.  Rows 64 .. m - 1 (at most 16: m <= 80): lane (g, r) = (lane >> 4, lane & 15) works on
-  // row 64 + r, and the four lane groups take DIFFERENT column batches of one trip (eleven rows on a row-per-lane mapping
-  // would pay a whole wave-instruction stream for 17 % of its lanes)
-  const int i0 = lane, i1 = 64 + (lane & 15), g1 = lane >> 4;
-  const bool r0 = i0 < m, r1 = i1 < m;
-  const bool two = m > 64;   // wave-uniform
-  double c0 = r0 ? bv[i0] : 0.0, c1 = r1 ? bv[i1] : 0.0;   // c1, dr1, t1: replicated in the four lanes of a row
-  double dr0 = 1.0, dr1 = 1.0;   // 1 / L_kk of this lane's rows
-  bool bad = false;
-  for (int j = lane; j < m + 8; j += 64) lcol[j] = 0.0;
-  for (int k = 0; k < m; ++k) {
-    const double d = S[(size_t)k * ms + k];
-    bad = bad || !(d > 0.0);
-    double rp = __builtin_amdgcn_rsq(d);            // 1 / sqrt(d): hardware seed + two Newton steps (relative error < 1e-16)
-    rp = rp * fma(-0.5 * d * rp, rp, 1.5);
-    rp = rp * fma(-0.5 * d * rp, rp, 1.5);
-    const bool u0 = r0 && i0 > k, u1 = r1 && i1 > k;
-    const double l0 = u0 ? S[(size_t)i0 * ms + k] * rp : 0.0;
-    const double l1 = u1 ? S[(size_t)i1 * ms + k] * rp : 0.0;
-    const double ck = readlane_f64(k < 64 ? c0 : c1, k & 63);   // (row 64 + r: lane r of group 0)
-    const double yk = ck * rp;
-    c0 = (i0 == k) ? yk : fma(-l0, yk, c0);
-    c1 = (i1 == k) ? yk : fma(-l1, yk, c1);
-    dr0 = (i0 == k) ? rp : dr0;
-    dr1 = (i1 == k) ? rp : dr1;
-    if (u0) { S[(size_t)i0 * ms + k] = l0; lcol[i0] = l0; }
-    if (u1 && g1 == 0) { S[(size_t)i1 * ms + k] = l1; lcol[i1] = l1; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // one wave: its LDS operations complete in order
-    // trailing columns in batches of eight, WITHOUT per-element predicates: rows at or above the pivot carry l = 0 (no-ops),
-    // entries above the diagonal and the columns past m - 1 that a batch reaches (row stride ms >= m + 7, lcol: m + 8) are
-    // scribbled on and never read
-    if (r0) {
-      double *row = S + (size_t)i0 * ms;
-      for (int j0 = k + 1; j0 < m; j0 += 8) {
-        // (requesting the next batch before this one's stores would save about a tenth of the solve, but its 16 extra VGPRs
-        // take the kernel past 128 and the leaf levels, which share it, from four waves per SIMD to three: measured, dropped)
-        double lj[8], a0[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) lj[q] = lcol[j0 + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a0[q] = row[j0 + q];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) row[j0 + q] = fma(-l0, lj[q], a0[q]);
-      }
-    }
-    if (two) {   // wave-uniform
-      if (r1) {
-        double *row = S + (size_t)i1 * ms;
-        for (int j0 = k + 1 + 8 * g1; j0 < m; j0 += 32) {
-          double lj[8], a1[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) lj[q] = lcol[j0 + q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) a1[q] = row[j0 + q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) row[j0 + q] = fma(-l1, lj[q], a1[q]);
-        }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  }
-  if (bad && lane == 0) *fail = 1;
-  // S now holds L below the diagonal (column k scaled by 1 / L_kk); c = L^{-1} b.  Backward: w_k = t_k / L_kk, t_j -= L_kj w_k
-  double t0 = r0 ? c0 + zg[i0] : 0.0, t1 = r1 ? c1 + zg[i1] : 0.0;
-  for (int k = m - 1; k >= 0; --k) {
-    const double wk = readlane_f64(k < 64 ? t0 : t1, k & 63) * readlane_f64(k < 64 ? dr0 : dr1, k & 63);
-    t0 = (i0 == k) ? wk : ((r0 && i0 < k) ? fma(-S[(size_t)k * ms + i0], wk, t0) : t0);
-    if (two) t1 = (i1 == k) ? wk : ((r1 && i1 < k) ? fma(-S[(size_t)k * ms + i1], wk, t1) : t1);
-  }
-  if (r0) bv[i0] = t0;
-  if (r1 && g1 == 0) bv[i1] = t1;
-}
-
-struct SampleArgs {
-  const Blk *blks;
-  const int *anc_idx;
-  const int *dch_idx;
-  const int *list;
-  int nlist;
-  const double *panels;  // param_data slot
-  double *w;
-  const double *y, *xb, *z;
-  const int *mv;
-  const unsigned char *obs;
-  double *acc;           // message arena
-  int *errflag;
-  double *scratch;       // BIG: staged S matrix
-  long long scratch_stride;
-  int maxP, maxM, maxLd;
-  int do_gram;
-  int no_fwd;   // limited_tree: a block's record goes to its single parent only, nothing is forwarded from its children
-  int lds_sq;   // BIG: 2 = the posterior precision lives in LDS after the vectors (maxM x (maxM | 1) + maxM doubles) and ONE wave
-                // factorises and solves there (wave_chol_solve_lds); 0 = scratch arena + workgroup-wide loops
-  double *s0;              // theta-only part Ri' Ri of every reference block's posterior precision, cached like the records'
-  const long long *s0off;  // Gram parts: per block, offset into s0 (row stride m) or -1
-  double tausq_inv[QMAX];
-};
-
-// NOREF: the level holds non-reference blocks only (the host knows): the reference branch -- whose blocked factorisation takes
-// 224 VGPRs -- is compiled out, so that leaf levels keep four waves per SIMD
-template <bool BIG, bool NOREF = false>
-__global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
-  __shared__ int s_fail;
-  __shared__ long long s_choff[16];    // record offsets of the first direct children (one read per block instead of one per entry)
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int maxP = A.maxP, maxM = A.maxM;
-  double *wv = lds;                    // maxP + maxM
-  double *tv = wv + (maxP + maxM);     // maxM   N w_pa
-  double *ev = tv + maxM;              // maxM   Ri w_u + N w_pa
-  double *bv = ev + maxM;              // maxM   rhs / solution
-  double *av = bv + maxM;              // maxM   per-ancestor temp
-  double *seg = av + maxM;             // MAXJ * maxM: seg[t][r] = sum_j N[r][oa_t + j] w_a[j], later ev[r] - seg[t][r]
-  double *Np = seg + (size_t)MAXJ * maxM;   // !BIG: maxM * maxLd panel copy
-  double *S = BIG ? (A.lds_sq ? Np : A.scratch + (size_t)blockIdx.x * A.scratch_stride) : (Np + (size_t)maxM * A.maxLd);
-
-  STAMP_DECL
-  int st_lev = 0;
-  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
-    const int b = A.list[li];
-    const Blk B = A.blks[b];
-    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
-    st_lev = B.level;
-    __syncthreads();
-    STAMP(7);
-    if (tid < J) {
-      const int a = A.anc_idx[B.anc_ptr + tid];
-      s_am[tid] = A.blks[a].m;
-      s_arow[tid] = A.blks[a].row0;
-    }
-    if (tid == 0) s_fail = 0;
-    if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      long long ao = 0;
-      for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
-      s_ao[J] = o; s_aoff[J] = ao;
-    }
-    __syncthreads();
-    for (int t = 0; t < J; ++t) {
-      const long long r0 = s_arow[t];
-      for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[r0 + i];
-    }
-    const double *pg = A.panels + B.panel_off;
-    const double *N;  // m x ld, row-major: [ -Ri*H | Ri or r ]
-    if (BIG) {
-      N = pg;
-    } else {
-      for (int idx = tid; idx < m * ld; idx += NT) Np[idx] = pg[idx];
-      N = Np;
-    }
-    __syncthreads();
-    for (int i0 = 4 * wid; i0 < m; i0 += 4 * (NT / 64)) {   // four rows per trip: their loads travel together
-      double a4[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int k = lane; k < P; k += 64) {
-        const double wk = wv[k];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (i0 + q < m) a4[q] += N[(size_t)(i0 + q) * ld + k] * wk;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double r = wave_sum(a4[q]);
-        if (lane == 0 && i0 + q < m) tv[i0 + q] = r;
-      }
-    }
-    __syncthreads();
-
-    STAMP(0);
-    if (!NOREF && B.isref) {
-      const double *Ri = N + P;  // Ri[i][j] = N[i*ld + P + j]
-      // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
-      const int ms = (BIG && A.lds_sq) ? ((m + 7) | 1) : m;   // row stride of S
-      const long long so = (BIG && A.s0off) ? A.s0off[b] : -1;
-#pragma unroll 4
-      for (int idx = tid; idx < m * m; idx += NT) {
-        const int i = idx / m, j = idx - i * m;
-        if (j <= i) {
-          double acc = 0.0;
-          if (so >= 0 && !A.do_gram) acc = A.s0[so + idx];   // Ri' Ri is a function of theta only
-          else {
-            for (int k = i; k < m; ++k) acc += Ri[(size_t)k * ld + i] * Ri[(size_t)k * ld + j];
-            if (so >= 0) A.s0[so + idx] = acc;
-          }
-          for (int c = 0; c < B.ndch; ++c) {
-            const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
-            acc += A.acc[co + B.acc_len + idx];
-          }
-          if (i == j) acc += A.tausq_inv[A.mv[B.row0 + i]];
-          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = acc; else S[(size_t)i * ms + j] = acc;
-        } else {
-          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = 0.0; else S[(size_t)i * ms + j] = 0.0;
-        }
-      }
-      // Smu_tot = A_u' w_pa + sum_children Smu_children + tausq_inv*(y - XB)   (:1062-1077)
-      for (int i = tid; i < m; i += NT) {
-        double acc = 0.0;
-        // - Ri' (N w_pa), walking Ri by ROWS (thread i reads entry i of row k: coalesced; same summation order as the column walk)
-        for (int k0 = 0; k0 < m; k0 += 8) {
-          double x[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) x[q] = (k0 + q < m && k0 + q >= i) ? Ri[(size_t)(k0 + q) * ld + i] : 0.0;
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (k0 + q < m && k0 + q >= i) acc -= x[q] * tv[k0 + q];
-        }
-        for (int c = 0; c < B.ndch; ++c) {
-          const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
-          acc += A.acc[co + B.acc_len + m * m + i];
-        }
-        const long long r = B.row0 + i;
-        acc += A.tausq_inv[A.mv[r]] * (A.y[r] - A.xb[r]);
-        bv[i] = acc;
-      }
-      if (BIG && A.lds_sq) {
-        // w_u = L^{-T} (L^{-1} Smu + z) by wave 0 alone, S in LDS (no workgroup barrier inside)
-        __syncthreads();
-        STAMP(1);
-        // (Np, not S: S is `lds_sq ? LDS : scratch arena`, a generic pointer -- the compiler would emit FLAT loads and stores,
-        // six times slower than ds_read / ds_write here)
-        if (m > 32) block_chol_solve_mfma(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail);   // (workgroup-uniform)
-        else if (wid == 0) wave_chol_solve_lds(Np, ms, Np + (size_t)maxM * ((maxM + 7) | 1), bv, A.z + B.row0, m, &s_fail, lane);
-      } else {
-      chol_lower_inplace(S, m, &s_fail);
-      // w_u = L^{-T} (L^{-1} Smu + z)   (= Sigi_chol' (Sigi_chol Smu + z), :1086)
-      for (int k = 0; k < m; ++k) {
-        __syncthreads();
-        const double xk = bv[k] / S[k * m + k];
-        __syncthreads();
-        if (tid == 0) bv[k] = xk;
-        for (int i = k + 1 + tid; i < m; i += NT) bv[i] -= S[i * m + k] * xk;
-      }
-      __syncthreads();
-      for (int i = tid; i < m; i += NT) bv[i] += A.z[B.row0 + i];
-      for (int k = m - 1; k >= 0; --k) {
-        __syncthreads();
-        const double xk = bv[k] / S[k * m + k];
-        __syncthreads();
-        if (tid == 0) bv[k] = xk;
-        for (int i = tid; i < k; i += NT) bv[i] -= S[k * m + i] * xk;
-      }
-      }
-      __syncthreads();
-      STAMP(2);
-      for (int i = tid; i < m; i += NT) {
-        wv[P + i] = bv[i];
-        A.w[B.row0 + i] = bv[i];
-      }
-      __syncthreads();
-      for (int i = tid; i < m; i += NT) {
-        double acc = tv[i];
-        for (int j = 0; j <= i; ++j) acc += Ri[(size_t)i * ld + j] * wv[P + j];
-        ev[i] = acc;
-      }
-    } else {
-      // non-reference rows (:1091-1155)
-      for (int i = tid; i < m; i += NT) {
-        const long long r = B.row0 + i;
-        const double ri = N[(size_t)i * ld + P];
-        const double tsq = A.tausq_inv[A.mv[r]];
-        const double sig = ri * ri + tsq;
-        if (!(sig > 0.0)) s_fail = 1;
-        const double mu = -ri * tv[i] + tsq * (A.y[r] - A.xb[r]);
-        const double c = 1.0 / sqrt(sig);
-        const double wi = c * c * mu + c * A.z[r];
-        wv[P + i] = wi;
-        A.w[r] = wi;
-        ev[i] = ri * wi + tv[i];
-      }
-    }
-    __syncthreads();
-    STAMP(3);
-    // messages to every ancestor (:1158-1207), summed with the direct children's accumulated messages
-    if (!A.do_gram) {
-      // Gram parts cached (Q4): only the vectors.  All ancestors at once, as in k_sample_lean: thread (row r, ancestor t)
-      // sums its segment N[r][oa_t ..] w_a, then thread k (a chain column) accumulates -sum_r N[r][k] (ev[r] - seg_t(k)[r])
-      for (int idx = tid; idx < m * J; idx += NT) {
-        const int r = idx / J, t = idx - r * J;
-        const int ma = s_am[t], oa = s_ao[t];
-        const double *row = N + (size_t)r * ld + oa;
-        const double *wa = wv + oa;
-        double a = 0.0;
-        for (int j0 = 0; j0 < ma; j0 += 8) {
-          double x[8];
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
-        }
-        seg[t * maxM + r] = ev[r] - a;
-      }
-      __syncthreads();
-      STAMP(4);
-      double *rec = A.acc + B.acc_off;
-      for (int k = tid; k < P; k += NT) {
-        int t = 0;
-        while (t + 1 < J && k >= s_ao[t + 1]) ++t;
-        const int ma = s_am[t], i = k - s_ao[t];
-        const double *avt = seg + t * maxM;
-        double a = 0.0;
-        for (int r0 = 0; r0 < m; r0 += 8) {
-          double x[8];
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < m) ? N[(size_t)(r0 + rr) * ld + k] : 0.0;
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) a -= x[rr] * ((r0 + rr < m) ? avt[r0 + rr] : 0.0);
-        }
-        for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
-          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
-          a += A.acc[C.acc_off + s_aoff[t] + ma * ma + i];
-        }
-        rec[s_aoff[t] + ma * ma + i] = a;
-      }
-      STAMP(5);
-      if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
-      continue;
-    }
-    long long off = 0;
-    for (int t = 0; t < J; ++t) {
-      const int ma = s_am[t], oa = s_ao[t];
-      for (int r = tid; r < m; r += NT) {
-        double acc = ev[r];
-        for (int j = 0; j < ma; ++j) acc -= N[(size_t)r * ld + oa + j] * wv[oa + j];
-        av[r] = acc;
-      }
-      __syncthreads();
-      double *out = A.acc + B.acc_off + off;
-      for (int idx = A.do_gram ? tid : ma * ma + tid; idx < ma * ma + ma; idx += NT) {
-        double acc = 0.0;
-        if (idx < ma * ma) {
-          const int i = idx / ma, j = idx - i * ma;
-          for (int r = 0; r < m; ++r) acc += N[(size_t)r * ld + oa + i] * N[(size_t)r * ld + oa + j];
-        } else {
-          const int i = idx - ma * ma;
-          for (int r = 0; r < m; ++r) acc -= N[(size_t)r * ld + oa + i] * av[r];
-        }
-        for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
-          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
-          acc += A.acc[C.acc_off + off + idx];
-        }
-        out[idx] = acc;
-      }
-      off += (long long)ma * ma + ma;
-      __syncthreads();
-    }
-    if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + (B.isref ? 10 : 11));
-  }
-  STAMP_FLUSH_LEVEL(st_lev);
-}
-
-
-// The theta-only parts of the generic path's message records -- Sigma_a = N_a' N_a per ancestor a, plus the direct children's
-// (spamtree_model.cpp:1162, 1190-1192) -- and of the posterior precision (Ri' Ri) on the FP64 matrix cores,
-// ahead of a sweep that then takes k_sample's cached branch.  k_sample's own do_gram branch builds them with one thread per
-// entry and a strided global walk per product: 35 ms for the leaf level of config #4 (16 384 blocks x 7 ancestors x 75 x 75
-// entries x 36 rows) against 2.2 ms for the sweep itself.  One workgroup per block; a task = one 16 x 16 tile (it >= jt) of
-// one ancestor's Gram matrix, tasks dealt over the four waves; both MFMA operands are rows of the block's panel, straight
-// from global memory / L2 (16 consecutive doubles per row: whole 128-byte segments).  Fixed summation order.
-struct GramBigArgs {
-  const Blk *blks;
-  const int *anc_idx, *dch_idx;
-  const int *list;
-  int nlist;
-  const double *panels;
-  double *acc;
-  double *s0;
-  const long long *s0off;
-  int no_fwd;
-};
-
-__global__ __launch_bounds__(NT) void k_gram_big(GramBigArgs A) {
-  __shared__ int s_am[MAXJ + 1], s_ao[MAXJ + 1], s_t0[MAXJ + 2];
-  __shared__ long long s_aoff[MAXJ + 1];
-  __shared__ long long s_choff[16];
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = A.list[blockIdx.x];
-  const Blk B = A.blks[b];
-  const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
-  const long long so = (B.isref && A.s0off) ? A.s0off[b] : -1;
-  if (tid < J) s_am[tid] = A.blks[A.anc_idx[B.anc_ptr + tid]].m;
-  if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
-  __syncthreads();
-  if (tid == 0) {
-    int o = 0, tasks = 0;
-    long long ao = 0;
-    for (int t = 0; t < J; ++t) {
-      const int nt = (s_am[t] + 15) >> 4;
-      s_ao[t] = o; s_aoff[t] = ao; s_t0[t] = tasks;
-      o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; tasks += nt * (nt + 1) / 2;
-    }
-    s_t0[J] = tasks;
-    if (so >= 0) { s_am[J] = m; s_ao[J] = P; s_aoff[J] = 0; const int nt = (m + 15) >> 4; tasks += nt * (nt + 1) / 2; }
-    s_t0[J + 1] = tasks;
-  }
-  __syncthreads();
-  const double *N = A.panels + B.panel_off;
-  double *rec = A.acc + B.acc_off;
-  const int ntask = s_t0[J + 1], ns = (m + 3) >> 2;
-  const int nch = A.no_fwd ? 0 : B.ndch;
-  for (int e = wid; e < ntask; e += NT / 64) {
-    int t = 0;
-    while (e >= s_t0[t + 1]) ++t;
-    int it = 0, pe = e - s_t0[t];
-    while ((it + 1) * (it + 2) / 2 <= pe) ++it;
-    const int jt = pe - it * (it + 1) / 2;
-    const int ma = s_am[t], oa = s_ao[t];
-    const int ci = 16 * it + l15, cj = 16 * jt + l15;
-    const double *ap = N + (size_t)l4 * ld + oa + min(ci, ma - 1), *bp = N + (size_t)l4 * ld + oa + min(cj, ma - 1);
-    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-    int st = 0;
-    for (; st + 4 <= ns; st += 4) {   // eight operand loads in flight per lane
-      double a4[4], b4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool rok = 4 * (st + q) + l4 < m;
-        a4[q] = (rok && ci < ma) ? ap[(size_t)4 * (st + q) * ld] : 0.0;
-        b4[q] = (rok && cj < ma) ? bp[(size_t)4 * (st + q) * ld] : 0.0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
-    }
-    for (; st < ns; ++st) {
-      const bool rok = 4 * st + l4 < m;
-      const double a1 = (rok && ci < ma) ? ap[(size_t)4 * st * ld] : 0.0, b1 = (rok && cj < ma) ? bp[(size_t)4 * st * ld] : 0.0;
-      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-    }
-    // C layout: entry (i = 16 it + 4 q + l4, j = 16 jt + l15); the mirrored entry of an off-diagonal tile gets the same value
-    const bool isS0 = t == J;
-    double *out = isS0 ? A.s0 + so : rec + s_aoff[t];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 16 * it + 4 * q + l4, j = cj;
-      if (i < ma && j < ma) {
-        double v = c[q];
-        if (!isS0) {
-          for (int ch = 0; ch < nch; ++ch) {
-            const long long co = ch < 16 ? s_choff[ch] : A.blks[A.dch_idx[B.dch_ptr + ch]].acc_off;
-            v += A.acc[co + s_aoff[t] + (size_t)i * ma + j];
-          }
-        }
-        out[(size_t)i * ma + j] = v;
-        if (it != jt) out[(size_t)j * ma + i] = v;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase B, fast path: one workgroup per column group (same groups as k_factor_mfma).  A sibling group of
-// non-reference blocks is treated as ONE block with a diagonal Ri: the Gram of the stacked panel rows is the sum
-// of the siblings' messages, so the group writes one message record (at its first block) instead of one per block.
-// Gram matrices N_a' N_a run on the FP64 matrix cores; the m x m posterior Cholesky and both triangular solves
-// run in the registers of wave 0.
-// ---------------------------------------------------------------------------------------------------------------
-struct SampleFastArgs {
-  const Blk *blks;
-  const int *anc_idx, *dch_idx;
-  const Grp *grps;
-  int ngrp;
-  const double *panels;
-  double *w;
-  const double *y, *xb, *z;
-  const int *mv;
-  double *acc;
-  int *errflag;
-  const long long *gdesc;   // group descriptors of this launch's first group onwards
-  int gd_stride;
-  int ldN, Mr4, Mrows, maxP, av_dbl;   // Mrows: staged panel rows (the level's largest group)   // av_dbl: doubles of the per-ancestor vectors / elimination scratch (>= 32 J, >= 224)
-  int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
-  int no_fwd;    // limited_tree: nothing is forwarded from the children's records
-  double tausq_inv[QMAX];
-};
-
-__global__ __launch_bounds__(NT, 3) void k_sample_mfma(SampleFastArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
-  __shared__ long long s_bpan[32], s_brow[32];
-  __shared__ int s_bld[32];
-  __shared__ int s_fail;
-  __shared__ long long s_coff[64];               // message records of the direct children
-  __shared__ int s_nch;
-  __shared__ long long s_gd[GD_MAXW];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int ldN = A.ldN, Mr4 = A.Mr4;
-  double *Np = lds;                              // maxM x ldN (no pad rows: the Gram tiles mask rows >= M)
-  double *wv = Np + (size_t)A.Mrows * ldN + 32;  // maxP + 32 : ancestors' w, then the group's new w
-  double *tv = wv + A.maxP + 32, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32;
-  double *av = zc + 32;                          // MAXJ x 32
-  int *colblk = (int *)(av + A.av_dbl);          // 32 ints
-  double *S = av + A.av_dbl + 16;                // reference levels only: maxM x CH_LD
-  double *Li = S;                                // chol(S)^{-1} replaces S (the elimination reads S once, writes at the end)
-
-  int gidx = blockIdx.x;
-  {
-    const int per = A.ngrp >> 3;
-    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-  }
-  STAMP_DECL
-  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
-  __syncthreads();
-  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
-  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
-  const int M = G.M, P = G.P, J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
-  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
-  if (tid < 32) {
-    const int j = tid;
-    if (j < M) {
-      const long long r = G.row0 + j;
-      tsq[j] = A.tausq_inv[A.mv[r]]; yx[j] = A.y[r] - A.xb[r]; zc[j] = A.z[r];
-      int bi = 0;
-      while (bi + 1 < G.nblk && r >= s_gd[8 + 4 * J + 3 * (bi + 1) + 1]) ++bi;
-      colblk[j] = bi;
-    } else {
-      tsq[j] = 0.0; yx[j] = 0.0; zc[j] = 0.0; colblk[j] = 0;
-    }
-  }
-  __syncthreads();
-  for (int k = tid; k < P; k += NT) {
-    int t = 0;
-    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
-    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
-  }
-  STAMP(0);
-  // panel rows -> LDS (row j of the group = one panel row of its block); pad rows / columns zero.
-  // Each wave takes rows wid, wid+4, ...; all loads of four rows are issued before the first LDS store.
-  const int rowlen = P + (refgrp ? M : 1);
-  for (int jb = 0; jb < Mr4; jb += 16) {
-    double tmp[4][4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = jb + wid + 4 * rr;
-      const int jc = min(j, M - 1);
-      const int bi = colblk[jc];
-      const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = lane + 64 * c;
-        tmp[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = jb + wid + 4 * rr;
-      if (j < M) {
-        double *dst = Np + (size_t)j * ldN;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int k = lane + 64 * c;
-          if (k < ldN) dst[k] = tmp[rr][c];
-        }
-        for (int k = 256 + lane; k < ldN; k += 64) dst[k] = 0.0;
-      }
-    }
-  }
-  for (int j = wid; j < M; j += NT / 64) {          // rows longer than 256 columns (P + M > 256)
-    const int bi = colblk[j];
-    const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + j - s_brow[bi]) * s_bld[bi];
-    for (int k = 256 + lane; k < rowlen; k += 64) Np[(size_t)j * ldN + k] = src[k];
-  }
-  __syncthreads();
-  STAMP(1);
-  for (int j = wid; j < M; j += NT / 64) {
-    double a = 0.0;
-    const double *row = Np + (size_t)j * ldN;
-    for (int k = lane; k < P; k += 64) a += row[k] * wv[k];
-    a = wave_sum(a);
-    if (lane == 0) tv[j] = a;
-  }
-  __syncthreads();
-  STAMP(2);
-  if (refgrp) {
-    const double *Ri = Np + P;   // Ri[i][j] = Np[i*ldN + P + j]
-    for (int idx = tid; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      double a = 0.0;
-      if (j <= i) {
-        double ch[4];   // the children's records: four loads in flight, fixed summation order
-        for (int c0 = 0; c0 < s_nch; c0 += 4) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
-          if (c0 == 0) for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-        }
-        if (s_nch == 0) for (int k = i; k < M; ++k) a += Ri[(size_t)k * ldN + i] * Ri[(size_t)k * ldN + j];
-        if (i == j) a += tsq[i];
-      }
-      S[i * CH_LD + j] = a;
-    }
-    if (tid < M) {
-      const int i = tid;
-      double a = 0.0;
-      for (int k = i; k < M; ++k) a -= Ri[(size_t)k * ldN + i] * tv[k];
-      double ch[4];
-      for (int c0 = 0; c0 < s_nch; c0 += 4) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-      }
-      bv[i] = a + tsq[i] * yx[i];
-    }
-  }
-  STAMP(3);
-  // Gram part of the message records, [ N_a' N_a ] + the children's records (spamtree_model.cpp:1158-1207); it does not
-  // depend on the draw and is skipped while it is still valid for the accepted theta
-  double *rec = A.acc + B0.acc_off;
-  const int nsteps = Mr4 >> 2;
-  if (A.do_gram) {
-    for (int u = wid; u < J * 4; u += NT / 64) {
-      const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
-      const int ma = s_am[t], oa = s_ao[t];
-      if (it * 16 >= ma || jt * 16 >= ma) continue;
-      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-      const double *ap = Np + (size_t)l4 * ldN + oa + it * 16 + l15;
-      const double *bp = Np + (size_t)l4 * ldN + oa + jt * 16 + l15;
-      for (int st = 0; st < nsteps; ++st) {
-        const bool rok = 4 * st + l4 < M;   // rows >= M are not staged; columns past the ancestor's m only feed discarded entries
-        const double av_ = rok ? ap[0] : 0.0, bv_ = rok ? bp[0] : 0.0;
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av_, bv_, c, 0, 0, 0);
-        ap += 4 * ldN; bp += 4 * ldN;
-      }
-      double *out = rec + s_aoff[t];
-      // children's records: all loads of a chunk of four children are issued together (fixed summation order)
-      double chv[4] = {0.0, 0.0, 0.0, 0.0};
-      const int nfw = A.no_fwd ? 0 : s_nch;
-      for (int c0 = 0; c0 < nfw; c0 += 4) {
-        double ld4[4][4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-            ld4[cc][r] = (c0 + cc < nfw && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, nfw - 1)] + s_aoff[t] + i * ma + j] : 0.0;
-          }
-        }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) chv[r] += ld4[cc][r];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-        if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
-      }
-    }
-  }
-  if (refgrp) {
-    // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I]: two small matrix-vector products
-    // instead of a forward and a backward substitution (m barrier steps each)
-    if (M <= 27) {
-      // one wave, registers only (wave_chol_solve): the other waves wait
-      __syncthreads();   // S, bv complete
-      if (tid < 64) wave_chol_solve<27>(S, bv, zc, wv + P, M, &s_fail, tid);
-    } else {
-      team_chol_eliminate<5, NT>(S, Li, M, M, av, &s_fail, tid);
-      if (tid < M) {
-        double a = zc[tid];
-        for (int j = 0; j <= tid; ++j) a += Li[tid * CH_LD + j] * bv[j];
-        ev[tid] = a;
-      }
-      __syncthreads();
-      if (tid < M) {
-        double a = 0.0;
-        for (int i = tid; i < M; ++i) a += Li[i * CH_LD + tid] * ev[i];
-        wv[P + tid] = a;
-      }
-    }
-  }
-  __syncthreads();
-  STAMP(4);
-  if (refgrp) {
-    const double *Ri = Np + P;
-    if (tid < M) {
-      const int i = tid;
-      A.w[G.row0 + i] = wv[P + i];
-      double a = tv[i];
-      for (int j = 0; j <= i; ++j) a += Ri[(size_t)i * ldN + j] * wv[P + j];
-      ev[i] = a;
-    }
-  } else {
-    if (tid < M) {
-      const int j = tid;
-      const double rj = Np[(size_t)j * ldN + P];
-      const double sig = rj * rj + tsq[j];
-      if (!(sig > 0.0)) s_fail = 1;
-      const double mu = -rj * tv[j] + tsq[j] * yx[j];
-      const double c = 1.0 / sqrt(sig);
-      const double wj = c * c * mu + c * zc[j];
-      wv[P + j] = wj;
-      A.w[G.row0 + j] = wj;
-      ev[j] = rj * wj + tv[j];
-    }
-  }
-  __syncthreads();
-  // av[t][r] = ev[r] - sum_j N[r][oa_t + j] w_a[j]  for every ancestor t
-  for (int idx = tid; idx < J * 32; idx += NT) {
-    const int t = idx >> 5, r = idx & 31;
-    double a = 0.0;
-    if (r < M) {
-      a = ev[r];
-      const double *row = Np + (size_t)r * ldN + s_ao[t];
-      const double *wa = wv + s_ao[t];
-      for (int j = 0; j < s_am[t]; ++j) a -= row[j] * wa[j];
-    }
-    av[idx] = a;
-  }
-  __syncthreads();
-  STAMP(5);
-  // vector part of the records: -N_a' av_a + the children's
-  for (int idx = tid; idx < J * 32; idx += NT) {
-    const int t = idx >> 5, i = idx & 31;
-    const int ma = s_am[t], oa = s_ao[t];
-    if (i < ma) {
-      double a = 0.0;
-      double ch[4];   // the children's vectors: requested before the dot product, added after it in a fixed order
-      const int nch = A.no_fwd ? 0 : s_nch;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
-      for (int r = 0; r < M; ++r) a -= Np[(size_t)r * ldN + oa + i] * av[t * 32 + r];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-      for (int c0 = 4; c0 < nch; c0 += 4) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nch) ? A.acc[s_coff[min(c0 + cc, nch - 1)] + s_aoff[t] + ma * ma + i] : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-      }
-      rec[s_aoff[t] + ma * ma + i] = a;
-    }
-  }
-  STAMP(6);
-  STAMP_FLUSH;
-  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase B, the theta-only part of the messages on its own: Gram part of a group's records, N_a' N_a + the children's
-// (spamtree_model.cpp:1162, 1190-1192: G_u[a, a]; SURVEY.md Q4: it depends on the accepted theta only).  Launched per level,
-// leaves first, on the first sweep after a factorisation of the accepted slot; the sweep itself then always takes the lean
-// kernels.  The panel is NOT staged: a wave owns one 16 x 16 tile of one ancestor's Gram matrix and reads its MFMA operands
-// straight from global memory / L2 (16 consecutive doubles per panel row and lane group), every load of the tile in
-// flight before the first MFMA; LDS holds the descriptor only, so eight workgroups share a CU.  Same arithmetic and
-// summation order as the Gram section of k_sample_mfma (bit-identical records).
-__global__ __launch_bounds__(NT, 6) void k_gram(SampleFastArgs A) {
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
-  __shared__ long long s_bpan[32], s_brow[32];
-  __shared__ int s_bld[32];
-  __shared__ long long s_coff[64];
-  __shared__ long long s_gd[GD_MAXW];
-  __shared__ long long s_rowoff[32];   // panel offset of the group's row r
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  int gidx = blockIdx.x;
-  {
-    const int per = A.ngrp >> 3;
-    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-  }
-  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
-  __syncthreads();
-  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
-  const int M = B0.M, J = B0.nanc;
-  __syncthreads();
-  if (tid < 32) {
-    long long off = 0;
-    if (tid < M) {
-      const long long r = B0.row0 + tid;
-      int bi = 0;
-      while (bi + 1 < B0.nblk && r >= s_brow[bi + 1]) ++bi;
-      off = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
-    }
-    s_rowoff[tid] = off;
-  }
-  __syncthreads();
-  const int nsteps = (M + 3) >> 2;          // <= 8
-  const int nfw = A.no_fwd ? 0 : B0.ndch;
-  double *rec = A.acc + B0.acc_off;
-  for (int u = wid; u < J * 4; u += NT / 64) {
-    const int t = u >> 2, it = (u >> 1) & 1, jt = u & 1;
-    const int ma = s_am[t], oa = s_ao[t];
-    if (it * 16 >= ma || jt * 16 >= ma) continue;
-    double av_[8], bv_[8];
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      const int r = 4 * st + l4;
-      const bool rok = st < nsteps && r < M;   // columns past the ancestor's m only feed discarded entries
-      const double *row = A.panels + s_rowoff[min(r, 31)] + oa + l15;
-      av_[st] = rok ? row[it * 16] : 0.0;
-      bv_[st] = rok ? row[jt * 16] : 0.0;
-    }
-    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int st = 0; st < 8; ++st)
-      if (st < nsteps) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av_[st], bv_[st], c, 0, 0, 0);
-    double *out = rec + s_aoff[t];
-    double chv[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int c0 = 0; c0 < nfw; c0 += 4) {   // children's records: chunks of four in flight, fixed summation order
-      double ld4[4][4];
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-          ld4[cc][r] = (c0 + cc < nfw && i < ma && j < ma) ? A.acc[s_coff[min(c0 + cc, nfw - 1)] + s_aoff[t] + i * ma + j] : 0.0;
-        }
-      }
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) chv[r] += ld4[cc][r];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-      if (i < ma && j < ma) out[i * ma + j] = c[r] + chv[r];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase B, fast path, sweeps that keep the cached Gram parts (do_gram == 0: every sweep between two accepted theta).
-// Same results as k_sample_mfma up to rounding, but the panel is never staged in LDS: it is read twice from global
-// memory (L2 / Infinity Cache the second time) with a thread mapping chosen per pass --
-//   pass 1: thread (row r, ancestor t) sums its 25-or-so products N[r][oa_t + j] w_a[j]: the segment sums give both
-//           tv = N w_pa (their sum over t) and, later, av_t = ev - N_t w_t, with no cross-lane reduction;
-//   pass 2: thread k (a chain column) accumulates -sum_r N[r][k] av_t(k)[r]: coalesced rows, no reduction either.
-// LDS holds vectors only (plus the m x m posterior precision of reference blocks): ~6-19 KB instead of 50-55 KB, so
-// 6-8 workgroups share a CU and their latency chains overlap.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
-  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
-  __shared__ int s_bld[32], s_cb[32];
-  __shared__ int s_fail;
-  __shared__ long long s_coff[64];
-  __shared__ int s_nch;
-  __shared__ long long s_gd[GD_MAXW];
-
-  const int tid = threadIdx.x;
-  double *wv = lds;                                  // maxP + 32 : ancestors' w, then the group's new w
-  double *seg = wv + A.maxP + 32;                    // av_dbl : seg[t][r], later av[t][r]; elimination scratch in between
-  double *tv = seg + A.av_dbl + 16, *ev = tv + 32, *bv = ev + 32, *tsq = bv + 32, *yx = tsq + 32, *zc = yx + 32, *rjv = zc + 32;
-  double *Rc = rjv + 32;                             // reference levels only: Ri, 32 x CH_LD
-  double *S = Rc + 32 * CH_LD;                       // 32 x CH_LD: posterior precision, then its inverse Cholesky factor
-
-  int gidx = blockIdx.x;
-  {
-    const int per = A.ngrp >> 3;
-    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-  }
-  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
-  __syncthreads();
-  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
-  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
-  const int M = G.M, P = G.P, J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
-  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
-  if (tid >= 32 && tid < 64) {
-    const int j = tid - 32;
-    double t_ = 0.0, y_ = 0.0, z_ = 0.0, r_ = 0.0;
-    int bi = 0;
-    long long ro = 0;
-    if (j < M) {
-      const long long r = G.row0 + j;
-      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
-      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
-      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
-      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
-      if (!refgrp) r_ = A.panels[ro + P];
-    }
-    tsq[j] = t_; yx[j] = y_; zc[j] = z_; rjv[j] = r_; s_cb[j] = bi; s_rowoff[j] = ro;
-  }
-  __syncthreads();
-  for (int k = tid; k < P; k += NT) {
-    int t = 0;
-    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
-    wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
-  }
-  if (refgrp) {   // Ri -> LDS (rows of the panel's last M columns)
-    for (int idx = tid; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      Rc[i * CH_LD + j] = (j <= i) ? A.panels[s_rowoff[i] + P + j] : 0.0;
-    }
-  }
-  __syncthreads();
-  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
-  for (int idx = tid; idx < M * J; idx += NT) {
-    const int r = idx / J, t = idx - r * J;
-    const int ma = s_am[t], oa = s_ao[t];
-    const double *row = A.panels + s_rowoff[r] + oa;
-    const double *wa = wv + oa;
-    double a = 0.0;
-    for (int j0 = 0; j0 < ma; j0 += 16) {   // two batches of loads for the usual 25-row ancestor
-      double x[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
-    }
-    seg[t * 32 + r] = a;
-  }
-  __syncthreads();
-  if (tid < M) {
-    double a = 0.0;
-    for (int t = 0; t < J; ++t) a += seg[t * 32 + tid];
-    tv[tid] = a;
-  }
-  __syncthreads();
-  if (refgrp) {
-    for (int idx = tid; idx < M * M; idx += NT) {
-      const int i = idx / M, j = idx - i * M;
-      double a = 0.0;
-      if (j <= i) {
-        double ch[4];   // the children's records: four loads in flight, fixed summation order
-        for (int c0 = 0; c0 < s_nch; c0 += 4) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
-          if (c0 == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-        }
-        if (s_nch == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
-        if (i == j) a += tsq[i];
-      }
-      S[i * CH_LD + j] = a;
-    }
-    if (tid < M) {
-      const int i = tid;
-      double a = 0.0;
-      for (int k = i; k < M; ++k) a -= Rc[k * CH_LD + i] * tv[k];
-      double ch[4];
-      for (int c0 = 0; c0 < s_nch; c0 += 4) {
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-      }
-      bv[i] = a + tsq[i] * yx[i];
-    }
-    // w_u = L^{-T} (L^{-1} Smu + z) with Li = L^{-1} from the elimination of [S | I] (scratch: the pivot cells live after
-    // the segment sums, which stay intact)
-    double *pub = seg + 32 * J;
-    if (M <= 27) {
-      // one wave, registers only: elimination with the right-hand side riding along, backward substitution by wave sums
-      __syncthreads();   // S, bv complete
-      if (tid < 64) wave_chol_solve<27>(S, bv, zc, wv + P, M, &s_fail, tid);
-      __syncthreads();
-    } else {
-      team_chol_eliminate<5, NT>(S, S, M, M, pub, &s_fail, tid);
-      if (tid < M) {
-        double a = zc[tid];
-        for (int j = 0; j <= tid; ++j) a += S[tid * CH_LD + j] * bv[j];
-        ev[tid] = a;
-      }
-      __syncthreads();
-      if (tid < M) {
-        double a = 0.0;
-        for (int i = tid; i < M; ++i) a += S[i * CH_LD + tid] * ev[i];
-        wv[P + tid] = a;
-      }
-      __syncthreads();
-    }
-    if (tid < M) {
-      const int i = tid;
-      A.w[G.row0 + i] = wv[P + i];
-      double a = tv[i];
-      for (int j = 0; j <= i; ++j) a += Rc[i * CH_LD + j] * wv[P + j];
-      ev[i] = a;
-    }
-  } else {
-    if (tid < M) {
-      const int j = tid;
-      const double rj = rjv[j];
-      const double sig = rj * rj + tsq[j];
-      if (!(sig > 0.0)) s_fail = 1;
-      const double mu = -rj * tv[j] + tsq[j] * yx[j];
-      const double c = 1.0 / sqrt(sig);
-      const double wj = c * c * mu + c * zc[j];
-      A.w[G.row0 + j] = wj;
-      ev[j] = rj * wj + tv[j];
-    }
-  }
-  __syncthreads();
-  // av[t][r] = ev[r] - seg[t][r]
-  for (int idx = tid; idx < J * 32; idx += NT) {
-    const int r = idx & 31;
-    seg[idx] = (r < M) ? ev[r] - seg[idx] : 0.0;
-  }
-  __syncthreads();
-  // ---- pass 2: vector part of the records, -N_a' av_a + the children's
-  double *rec = A.acc + B0.acc_off;
-  for (int k = tid; k < P; k += NT) {
-    int t = 0;
-    while (t + 1 < J && k >= s_ao[t + 1]) ++t;
-    const int ma = s_am[t], i = k - s_ao[t];
-    const double *avt = seg + t * 32;
-    double ch[4];   // the children's vectors: requested first, added after the dot product in a fixed order
-    const int nch = A.no_fwd ? 0 : s_nch;
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
-    double a = 0.0;
-    for (int r0 = 0; r0 < M; r0 += 8) {
-      double x[8];
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < M) ? A.panels[s_rowoff[min(r0 + rr, M - 1)] + k] : 0.0;
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) a -= x[rr] * avt[min(r0 + rr, 31)];
-    }
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-    for (int c0 = 4; c0 < nch; c0 += 4) {
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nch) ? A.acc[s_coff[min(c0 + cc, nch - 1)] + s_aoff[t] + ma * ma + i] : 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) a += ch[cc];
-    }
-    rec[s_aoff[t] + ma * ma + i] = a;
-  }
-  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase B, reference blocks of at most 27 rows, ONE BLOCK PER WAVE (four independent blocks per workgroup, no workgroup
-// barrier anywhere).  k_sample_lean gives a block 256 threads and eleven barriers for what is a chain of short dependent
-// steps (descriptor -> rows' data -> panel pass 1 -> children's records -> 25-pivot solve -> panel pass 2): a 55 us latency
-// chain per block with five of them in flight per CU.  Here a wave walks the same chain alone -- lane i owns row i: its
-// segment sums, row i of the posterior precision built straight into the registers the elimination works on
-// (wave_chol_solve_core), its draw -- with 11 KB of LDS, so twelve blocks are in flight per CU.  Same arithmetic and
-// summation orders as k_sample_lean (identical draws).  LDS operations of one wave execute in order: a wave-level
-// s_waitcnt separates the phases.
-// ---------------------------------------------------------------------------------------------------------------
-#define WSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-__global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_failw[NT / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int gidx = blockIdx.x * (NT / 64) + wid;
-  if (gidx >= A.ngrp) return;   // no workgroup barrier below: a wave without a block simply leaves
-  double *base = lds + (size_t)wid * A.ldN;          // this wave's LDS region (A.ldN doubles)
-  long long *s_gd = (long long *)base;               // the block's descriptor
-  double *wv = base + A.gd_stride;                   // maxP + 32 : ancestors' w, then the block's new w
-  double *seg = wv + A.maxP + 32;                    // av_dbl : seg[t][r], later av[t][r]
-  double *tv = seg + A.av_dbl, *ev = tv + 32;
-  double *Rc = ev + 32;                              // Mrows x CH_LD: Ri
-  if (lane == 0) s_failw[wid] = 0;
-  for (int i = lane; i < A.gd_stride; i += 64) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
-  WSYNC();
-  auto slo = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffLL)); };
-  auto shi = [](long long v) { return __builtin_amdgcn_readfirstlane((int)(v >> 32)); };
-  auto sll = [&](long long v) { return ((long long)shi(v) << 32) | (unsigned int)slo(v); };
-  const long long row0 = sll(s_gd[0]), acc_off = sll(s_gd[1]);
-  const int M = slo(s_gd[2]), P = shi(s_gd[2]), J = slo(s_gd[3]), level = shi(s_gd[4]);
-  const int nch = slo(s_gd[5]), acc_len = shi(s_gd[5]);
-  const long long *gb = s_gd + 8 + 4 * J;            // the block: panel offset, first row, ld
-  const long long bpan = sll(gb[0]);
-  const int bld = (int)sll(gb[2]);
-  const long long *coff = gb + 3;                    // message records of the direct children
-  auto am_of = [&](int t) { return (int)(s_gd[8 + 4 * t] & 0xffffffffLL); };
-  auto ao_of = [&](int t) { return (int)(s_gd[8 + 4 * t] >> 32); };
-  const bool row = lane < M;
-  const int li = min(lane, 31);
-  double tsq = 0.0, yx = 0.0, zc = 0.0;
-  if (row) { const long long r = row0 + lane; tsq = A.tausq_inv[A.mv[r]]; yx = A.y[r] - A.xb[r]; zc = A.z[r]; }
-  for (int k = lane; k < P; k += 64) {
-    int t = 0;
-    for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
-    wv[k] = A.w[s_gd[8 + 4 * t + 1] + (k - ao_of(t))];
-  }
-  for (int idx = lane; idx < M * M; idx += 64) {     // Ri -> LDS (the panel's last M columns)
-    const int i = idx / M, j = idx - i * M;
-    Rc[i * CH_LD + j] = (j <= i) ? A.panels[bpan + (size_t)i * bld + P + j] : 0.0;
-  }
-  WSYNC();
-  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
-  for (int idx = lane; idx < M * J; idx += 64) {
-    const int r = idx / J, t = idx - r * J;
-    const int ma = am_of(t), oa = ao_of(t);
-    const double *prow = A.panels + bpan + (size_t)r * bld + oa;
-    const double *wa = wv + oa;
-    double a = 0.0;
-    for (int j0 = 0; j0 < ma; j0 += 16) {
-      double x[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) x[jj] = (j0 + jj < ma) ? prow[j0 + jj] : 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
-    }
-    seg[t * 32 + r] = a;
-  }
-  WSYNC();
-  double tvi = 0.0;
-  if (row) { for (int t = 0; t < J; ++t) tvi += seg[t * 32 + lane]; tv[lane] = tvi; }
-  WSYNC();
-  // ---- row `lane` of the posterior precision Ri'Ri + the children's Gram parts + tausq_inv, straight into registers
-  double a[27];
-#pragma unroll
-  for (int j = 0; j < 27; ++j) a[j] = 0.0;
-  double bv = 0.0;
-  for (int k = 0; k < M; ++k) {                      // Ri[k][i] = 0 for k < i: the leading terms add exact zeros
-    const double rk = Rc[k * CH_LD + li];
-    bv -= rk * tv[k];
-#pragma unroll
-    for (int j = 0; j < 27; ++j) a[j] += rk * Rc[k * CH_LD + j];
-  }
-  for (int c = 0; c < nch; ++c) {                    // the children's records, fixed order
-    const double *rc = A.acc + coff[c] + acc_len;
-    double ch[27];
-#pragma unroll
-    for (int j = 0; j < 27; ++j) ch[j] = (row && j <= lane) ? rc[li * M + j] : 0.0;
-    const double cv = row ? rc[M * M + li] : 0.0;
-#pragma unroll
-    for (int j = 0; j < 27; ++j) a[j] += ch[j];
-    bv += cv;
-  }
-#pragma unroll
-  for (int j = 0; j < 27; ++j) {
-    if (j == lane) a[j] += tsq;
-    a[j] = (row && j <= lane) ? a[j] : (j == lane ? 1.0 : 0.0);
-  }
-  bv = row ? bv + tsq * yx : 0.0;
-  // ---- w_u = L^{-T} (L^{-1} b + z): elimination with the right-hand side riding along, backward substitution by wave sums
-  const double wnew = wave_chol_solve_core<27>(a, bv, zc, M, &s_failw[wid], lane);
-  if (row) { A.w[row0 + lane] = wnew; wv[P + lane] = wnew; }
-  WSYNC();
-  if (row) {
-    double e = tvi;
-    for (int j = 0; j <= lane; ++j) e += Rc[lane * CH_LD + j] * wv[P + j];
-    ev[lane] = e;
-  }
-  WSYNC();
-  for (int idx = lane; idx < J * 32; idx += 64) {    // av[t][r] = ev[r] - seg[t][r]
-    const int r = idx & 31;
-    seg[idx] = (r < M) ? ev[r] - seg[idx] : 0.0;
-  }
-  WSYNC();
-  // ---- pass 2: vector part of the records, -N_a' av_a + the children's
-  double *rec = A.acc + acc_off;
-  const int nfw = A.no_fwd ? 0 : nch;
-  for (int k = lane; k < P; k += 64) {
-    int t = 0;
-    for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
-    const int ma = am_of(t), i = k - ao_of(t);
-    const long long aoff = s_gd[8 + 4 * t + 3];
-    const double *avt = seg + t * 32;
-    double ch[4];
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nfw) ? A.acc[coff[min(cc, max(nfw - 1, 0))] + aoff + ma * ma + i] : 0.0;
-    double acc = 0.0;
-    for (int r0 = 0; r0 < M; r0 += 8) {
-      double x[8];
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < M) ? A.panels[bpan + (size_t)min(r0 + rr, M - 1) * bld + k] : 0.0;
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) acc -= x[rr] * avt[min(r0 + rr, 31)];
-    }
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) acc += ch[cc];
-    for (int c0 = 4; c0 < nfw; c0 += 4) {
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < nfw) ? A.acc[coff[min(c0 + cc, nfw - 1)] + aoff + ma * ma + i] : 0.0;
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) acc += ch[cc];
-    }
-    rec[aoff + ma * ma + i] = acc;
-  }
-  WSYNC();
-  if (lane == 0 && s_failw[wid]) atomicMin(A.errflag, level * 16 + 10);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase B, fast path, leaf (non-reference) groups on sweeps that keep the cached Gram parts.  The rows of a leaf group
-// are independent given the ancestors (diagonal Ri), so a wave owns whole rows: lanes hold the row's columns (coalesced
-// loads, registers only), the per-ancestor segment sums come from masked butterfly reductions, the draw, the residual
-// and the row's contribution -N[r][k] av_t(k)[r] to every chain column follow without leaving the wave; only the
-// column sums over the four waves go through LDS.  One pass over the panel, ~10 KB of LDS, one barrier pair.
-// ---------------------------------------------------------------------------------------------------------------
-// sum over the 64 lanes, returned wave-uniform, without touching the LDS crossbar: rotate-and-add inside each row of 16
-// lanes (DPP row_ror 8, 4, 2, 1), then the four row sums (lanes 0, 16, 32, 48) through v_readlane, added in that order
-__device__ __forceinline__ double dpp_ror_add(double x, const int ctrl_sel) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  int lo2, hi2;
-  if (ctrl_sel == 8) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false); }
-  else if (ctrl_sel == 4) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x124, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x124, 0xf, 0xf, false); }
-  else if (ctrl_sel == 2) { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x122, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x122, 0xf, 0xf, false); }
-  else { lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x121, 0xf, 0xf, false); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x121, 0xf, 0xf, false); }
-  return x + __hiloint2double(hi2, lo2);
-}
-__device__ __forceinline__ double wave_allsum(double x) {
-  x = dpp_ror_add(x, 8); x = dpp_ror_add(x, 4); x = dpp_ror_add(x, 2); x = dpp_ror_add(x, 1);
-  const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
-  return ((r0 + r1) + r2) + r3;
-}
-
-__global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
-  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
-  __shared__ int s_bld[32];
-  __shared__ int s_fail;
-  __shared__ long long s_coff[64];
-  __shared__ int s_nch;
-  __shared__ long long s_gd[GD_MAXW];
-  __shared__ double s_seg[NT / 64][MAXJ];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  double *wv = lds;                       // maxP + 32
-  double *red = wv + A.maxP + 32;         // 4 x 256: per-wave column sums
-  double *tsq = red + 4 * 256, *yx = tsq + 32, *zc = yx + 32;
-
-  int gidx = blockIdx.x;
-  {
-    const int per = A.ngrp >> 3;
-    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
-  }
-  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
-  __syncthreads();
-  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
-  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
-  const int M = G.M, P = G.P, J = B0.nanc;
-  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
-  if (tid >= 32 && tid < 64) {
-    const int j = tid - 32;
-    double t_ = 0.0, y_ = 0.0, z_ = 0.0;
-    long long ro = 0;
-    if (j < M) {
-      const long long r = G.row0 + j;
-      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
-      int bi = 0;
-      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
-      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
-      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
-    }
-    tsq[j] = t_; yx[j] = y_; zc[j] = z_; s_rowoff[j] = ro;
-  }
-  __syncthreads();
-  // this lane's columns k = lane + 64 c (P + 1 <= 256 columns: the host routes longer chains to k_sample_mfma)
-  int tk[4];
-  double wk[4], acc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int k = lane + 64 * c;
-    const int t = anc_of(s_ao, J, k);
-    tk[c] = k < P ? t : -1;
-    wk[c] = k < P ? A.w[s_arow[t] + (k - s_ao[t])] : 0.0;
-    acc[c] = 0.0;
-  }
-  const int lastc = P >> 6, lastl = P & 63;   // where column P (the row's r_j) lives
-#pragma unroll 1
-  for (int b = 0; b < 2; ++b) {
-    double v[4][4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = wid + 4 * (4 * b + rr);
-      const double *src = A.panels + s_rowoff[min(j, M - 1)];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int k = lane + 64 * c;
-        v[rr][c] = (j < M && k <= P) ? src[k] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = wid + 4 * (4 * b + rr);
-      if (j < M) {   // wave-uniform
-        // segment sums (every lane gets them), tv = their sum in ancestor order
-        double tvj = 0.0;
-        for (int t = 0; t < J; ++t) {
-          double x = 0.0;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) x += (tk[c] == t) ? v[rr][c] * wk[c] : 0.0;
-          x = wave_allsum(x);
-          if (lane == 0) s_seg[wid][t] = x;
-          tvj += x;
-        }
-        double rj = 0.0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) if (c == lastc) rj = __shfl(v[rr][c], lastl, 64);
-        const double sig = rj * rj + tsq[j];
-        if (!(sig > 0.0) && lane == 0) s_fail = 1;
-        const double mu = -rj * tvj + tsq[j] * yx[j];
-        const double cc = 1.0 / sqrt(sig);
-        const double wj = cc * cc * mu + cc * zc[j];
-        if (lane == 0) A.w[G.row0 + j] = wj;
-        const double evj = rj * wj + tvj;
-        // this row's share of the vector records: -N[j][k] (ev_j - seg_t(k)[j])
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (tk[c] >= 0) acc[c] -= v[rr][c] * (evj - s_seg[wid][tk[c]]);
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c) red[wid * 256 + lane + 64 * c] = acc[c];
-  __syncthreads();
-  double *rec = A.acc + B0.acc_off;
-  for (int k = tid; k < P; k += NT) {
-    const int t = anc_of(s_ao, J, k);
-    const int ma = s_am[t], i = k - s_ao[t];
-    double a = ((red[k] + red[256 + k]) + red[512 + k]) + red[768 + k];
-    for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
-    rec[s_aoff[t] + ma * ma + i] = a;
-  }
-  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 11);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Phase C: residual + quadratic form per block (spamtree_model.cpp:781-826)
-// ---------------------------------------------------------------------------------------------------------------
-struct LoglikArgs {
-  const Blk *blks;
-  const int *anc_idx;
-  const int *list;
-  int nlist;
-  const double *panels;
-  const double *w;
-  double *loglik_c;
-  int maxP, maxM;
-};
-
-__global__ __launch_bounds__(NT) void k_loglik(LoglikArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ];
-  __shared__ double s_red[NT / 64];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  double *wv = lds;
-  double *tv = wv + (A.maxP + A.maxM);
-  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
-    const int b = A.list[li];
-    const Blk B = A.blks[b];
-    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
-    __syncthreads();
-    if (tid < J) {
-      const int a = A.anc_idx[B.anc_ptr + tid];
-      s_am[tid] = A.blks[a].m;
-      s_arow[tid] = A.blks[a].row0;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-      s_ao[J] = o;
-    }
-    __syncthreads();
-    for (int t = 0; t < J; ++t)
-      for (int i = tid; i < s_am[t]; i += NT) wv[s_ao[t] + i] = A.w[s_arow[t] + i];
-    for (int i = tid; i < m; i += NT) wv[P + i] = A.w[B.row0 + i];
-    __syncthreads();
-    const double *N = A.panels + B.panel_off;
-    for (int i = wid; i < m; i += NT / 64) {
-      double acc = 0.0;
-      for (int k = lane; k < P; k += 64) acc += N[(size_t)i * ld + k] * wv[k];
-      acc = wave_sum(acc);
-      if (lane == 0) tv[i] = acc;
-    }
-    __syncthreads();
-    double part = 0.0;
-    for (int i = tid; i < m; i += NT) {
-      double acc = tv[i];
-      if (B.isref) {
-        for (int j = 0; j <= i; ++j) acc += N[(size_t)i * ld + P + j] * wv[P + j];
-      } else {
-        acc += N[(size_t)i * ld + P] * wv[P + i];
-      }
-      part += acc * acc;
-    }
-    const double wcore = block_sum(part, s_red);
-    if (tid == 0) A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
-  }
-}
-
-// Phase C for the column-group levels: one workgroup per group (a reference block, or <= 32 rows of sibling leaf blocks
-// which share their ancestors' w).  Every wave requests all of its panel rows before the first use (up to 8 rows x 5
-// pieces of 64 columns in flight per lane); a row of the panel is [ N_i | Ri_i 0 ] (reference) or [ N_i | r_i ] (leaf), so
-// the residual e_i = Ri (w_u - H w_pa) is one dot product of the row with [ w_pa ; w_u ].
-struct LoglikGrpArgs {
-  const Blk *blks;
-  const int *anc_idx;
-  const Grp *grps;
-  const int *list;   // group indices
-  int nlist;
-  const double *panels;
-  const double *w;
-  double *loglik_c;
-  int maxP;
-  const long long *gdesc;   // all group descriptors (indexed by the absolute group index in `list`)
-  int gd_stride;
-};
-
-__global__ __launch_bounds__(NT, 8) void k_loglik_grp(LoglikGrpArgs A) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ];
-  __shared__ long long s_bpan[32], s_brow[32];
-  __shared__ int s_bld[32], s_cb[32];
-  __shared__ double s_e2[32];
-  __shared__ long long s_gd[GD_MAXW];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  double *wv = lds;   // maxP + 32
-  {
-    const long long *gd = A.gdesc + (size_t)A.list[blockIdx.x] * A.gd_stride;
-    for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = gd[i];   // the group's descriptor: one round trip
-  }
-  __syncthreads();
-  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, nullptr, s_bpan, s_brow, s_bld, nullptr);
-  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
-  const int M = G.M, P = G.P, J = B0.nanc;
-  const bool refgrp = B0.isref != 0;
-  if (tid >= 128 && tid < 128 + 32) wv[P + tid - 128] = (tid - 128 < M) ? A.w[G.row0 + tid - 128] : 0.0;
-  if (tid >= 32 && tid < 64) {
-    const int j = tid - 32;
-    int bi = 0;
-    if (j < M) { const long long r = G.row0 + j; while (bi + 1 < G.nblk && r >= s_gd[8 + 4 * J + 3 * (bi + 1) + 1]) ++bi; }
-    s_cb[j] = bi;
-  }
-  __syncthreads();
-  // this wave's rows wid, wid + 4, ... in two batches of four rows; all of a batch's loads are issued before anything
-  // waits.  <= 64 VGPRs: eight workgroups per CU keep the memory system busy.
-  const int rowlen = P + (refgrp ? M : 1);
-#pragma unroll 1
-  for (int b = 0; b < 2; ++b) {
-    double v[4][5];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = wid + 4 * (4 * b + rr), jc = min(j, M - 1);
-      const int bi = s_cb[jc];
-      const double *src = A.panels + s_bpan[bi] + (size_t)(G.row0 + jc - s_brow[bi]) * s_bld[bi];
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        const int k = lane + 64 * c;
-        v[rr][c] = (j < M && k < rowlen) ? src[k] : 0.0;
-      }
-    }
-    if (b == 0) {
-      for (int k = tid; k < P; k += NT) {
-        int t = 0;
-        while (t + 1 < J && k >= s_ao[t + 1]) ++t;
-        wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int j = wid + 4 * (4 * b + rr);
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        const int k = lane + 64 * c;
-        const double wk = k < P ? wv[k] : (refgrp ? (k < rowlen ? wv[k] : 0.0) : wv[P + min(j, 31)]);
-        acc += v[rr][c] * wk;
-      }
-      acc = wave_sum(acc);
-      if (lane == 0 && j < 32) s_e2[j] = acc * acc;
-    }
-  }
-  __syncthreads();
-  if (tid < G.nblk) {
-    double wc = 0.0;
-    int cnt = 0;
-    for (int j = 0; j < M; ++j)
-      if (s_cb[j] == tid) { wc += s_e2[j]; ++cnt; }
-    A.loglik_c[G.blk0 + tid] = (double)cnt * HL2PI - 0.5 * wc;
-  }
-}
-
-// fixed-shape deterministic sums of two arrays: out[0] = sum a, out[1] = sum b.  Stage 1: SUM2_WG workgroups, each a
-// contiguous chunk (thread-strided partial sums, LDS tree); stage 2: one wave adds the SUM2_WG partials in order.
-#define SUM2_WG 64
-__global__ __launch_bounds__(NT) void k_sum2_partial(const double *a, const double *b, int n, double *partial) {
-  __shared__ double sa[NT], sb[NT];
-  const int chunk = (n + SUM2_WG - 1) / SUM2_WG;
-  const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
-  double xa = 0.0, xb = 0.0;
-  for (int i = lo + threadIdx.x; i < hi; i += NT) { xa += a[i]; xb += b[i]; }
-  sa[threadIdx.x] = xa; sb[threadIdx.x] = xb;
-  __syncthreads();
-  for (int s2 = NT / 2; s2 > 0; s2 >>= 1) {
-    if ((int)threadIdx.x < s2) { sa[threadIdx.x] += sa[threadIdx.x + s2]; sb[threadIdx.x] += sb[threadIdx.x + s2]; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sa[0]; partial[2 * blockIdx.x + 1] = sb[0]; }
-}
-__global__ void k_sum2_final(const double *partial, double *out) {
-  if (threadIdx.x < 2) {
-    double s2 = 0.0;
-    for (int g = 0; g < SUM2_WG; ++g) s2 += partial[2 * g + threadIdx.x];
-    out[threadIdx.x] = s2;
-  }
-}
-static void launch_sum2(hipStream_t st, const double *a, const double *b, int n, double *partial, double *out) {
-  hipLaunchKernelGGL(k_sum2_partial, dim3(SUM2_WG), dim3(NT), 0, st, a, b, n, partial);
-  hipLaunchKernelGGL(k_sum2_final, dim3(1), dim3(64), 0, st, partial, out);
-}
-
-// XB = X * Bcoeff[:, mv]   (spamtree_model.cpp:127, 1382); X is column-major n x p in device row order
-__global__ void k_xb(const double *X, const int *mv, const double *B, long long n, int p, double *xb) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double *bj = B + (size_t)p * mv[i];
-  double acc = 0.0;
-  for (int j = 0; j < p; ++j) acc += X[(size_t)j * n + i] * bj[j];
-  xb[i] = acc;
-}
-
-// partial sums for beta / tausq: per workgroup nq = p*q + q values; stage 2 reduces in workgroup order.
-#define STATS_WG 1024
-__global__ __launch_bounds__(NT) void k_stats(const double *X, const double *y, const double *w, const double *xb, const int *mv,
-                                               const unsigned char *obs, const long long *partner, long long n, int p, int q,
-                                               double *partial) {
-  __shared__ double s_red[NT / 64];
-  const int nq = p * q + q;
-  double acc[QMAX * 8 + QMAX];  // p <= 8 enforced on the host for this kernel
-  for (int k = 0; k < nq; ++k) acc[k] = 0.0;
-  const long long chunk = (n + gridDim.x - 1) / gridDim.x;
-  const long long lo = (long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
-  for (long long i = lo + threadIdx.x; i < hi; i += NT) {
-    if (!obs[i]) continue;
-    const int v = mv[i];
-    const double rw = y[i] - w[partner[i]];
-    for (int j = 0; j < p; ++j) acc[v * p + j] += X[(size_t)j * n + i] * rw;
-    const double e = y[i] - xb[i] - w[i];
-    acc[p * q + v] += e * e;
-  }
-  for (int k = 0; k < nq; ++k) {
-    const double s = block_sum(acc[k], s_red);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * nq + k] = s;
-  }
-}
-// one workgroup per statistic: fixed-shape tree over the STATS_WG partial sums (deterministic)
-__global__ __launch_bounds__(NT) void k_stats_final(const double *partial, int nwg, int nq, double *out) {
-  __shared__ double sm[NT];
-  const int k = blockIdx.x;
-  double s = 0.0;
-  for (int g = threadIdx.x; g < nwg; g += NT) s += partial[(size_t)g * nq + k];
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = NT / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[k] = sm[0];
-}
-
-__global__ void k_yhat(const double *xb, const double *w, const double *noise, const int *mv, long long n, const double *tsq_inv_q,
-                       double *yhat) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) yhat[i] = xb[i] + w[i] + noise[i] / sqrt(tsq_inv_q[mv[i]]);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// "Next" rows of SURVEY.md section 8f: the exported CrossCovarianceAG10 (covariance_functions.cpp:301-355) and
-// running posterior means of w / yhat over saved iterations (the use of list_mean, list_mean.cpp:10-40)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void k_cross_cov(const double *c1, const int *mv1, long long n1, const double *c2, const int *mv2, long long n2, CovPar cp,
-                            double *out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long j = blockIdx.y;
-  if (i < n1 && j < n2) out[j * n1 + i] = cov_entry(cp, c1[i], c1[n1 + i], mv1[i], c2[j], c2[n2 + j], mv2[j]);
-}
-// Posterior quantiles per row over the saved draws (list_qtile / prctile_stl, /root/reference/src/list_mean.cpp:62-137):
-// draws[d * n + row], d < keep.  A workgroup sorts the draws of R rows in LDS (bitonic, rows padded to Kpad = 2^k with +inf)
-// and applies the reference's interpolation rule between the two order statistics around r = q * keep.
-struct QtArgs {
-  const double *draws;
-  long long n;
-  int keep, Kpad, R;
-  double q;
-  double *out;
-};
-__global__ __launch_bounds__(NT) void k_qtile(QtArgs A) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, R = A.R, K = A.Kpad;
-  const long long row0 = (long long)blockIdx.x * R;
-  for (int idx = tid; idx < R * K; idx += NT) {
-    const int d = idx / R, r = idx - d * R;   // R consecutive rows of one draw: contiguous in memory
-    double v = __builtin_inf();
-    if (d < A.keep && row0 + r < A.n) v = A.draws[(size_t)d * A.n + row0 + r];
-    lds[(size_t)r * K + d] = v;
-  }
-  __syncthreads();
-  const int half = K >> 1;
-  for (int k = 2; k <= K; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int p = tid; p < R * half; p += NT) {
-        const int r = p / half, i = p - r * half;
-        const int i1 = 2 * j * (i / j) + (i % j), i2 = i1 + j;
-        double *a = lds + (size_t)r * K;
-        const double x = a[i1], y = a[i2];
-        const bool up = (i1 & k) == 0;
-        if ((x > y) == up) { a[i1] = y; a[i2] = x; }
-      }
-      __syncthreads();
-    }
-  }
-  if (tid < R && row0 + tid < A.n) {
-    const double *a = lds + (size_t)tid * K;
-    const int len = A.keep;
-    // prctile_stl: r = percent / 100 * len with percent = q * 100 (cqtile); every product rounded on its own -- a fused
-    // q * len - 1 would see 0.025 * 40 as 1 + 5.6e-17 and pick the other pair of order statistics
-    double r = A.q * 100.0, lower, upper;
-    asm volatile("" : "+v"(r));   // (an empty asm after each step keeps the optimiser from contracting across it)
-    r = r / 100.0;
-    asm volatile("" : "+v"(r));
-    r = r * (double)len;
-    asm volatile("" : "+v"(r));
-    if (r >= len / 2.0) {
-      const int lo = (int)fmax(r - 1.0, 0.0);
-      lower = a[lo];
-      upper = lo < len - 1 ? a[lo + 1] : lower;
-    } else {
-      const int up = (int)ceil(fmax(r - 1.0, 0.0));
-      upper = a[up];
-      lower = up > 0 ? a[up - 1] : upper;
-    }
-    const int k = (int)(r + 0.5);                    // implicit floor
-    r = r - k;
-    A.out[row0 + tid] = (0.5 - r) * lower + (0.5 + r) * upper;
-  }
-}
-
-__global__ void k_axpy_sum(double *acc, const double *x, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) acc[i] += x[i];
-}
+#include "sample_kernels.hpp"
+#include "misc_kernels.hpp"
 
 // ===============================================================================================================
 // host side
@@ -4311,34 +1309,7 @@ static int reset_err(st_handle h) {
 
 // sum-with-zeros exchange buffers: every entry is contributed by exactly one rank (replicated blocks by rank 0), so
 // an all-reduce(sum) reproduces the single-GPU arrays bit for bit, for any number of ranks and any reduction order
-__global__ void k_pack_comps(const double *logdet, const double *loglik, const unsigned char *mask, int nb, const int *err, int rank,
-                             int world, double *buf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nb) {
-    buf[i] = mask[i] ? logdet[i] : 0.0;
-    buf[nb + i] = mask[i] ? loglik[i] : 0.0;
-  }
-  if (i < world) buf[2 * nb + i] = (i == rank && err[0] != INT_MAX) ? (double)err[0] : 0.0;
-}
 // all-gather form of the exchange of w: a rank's slice of the gather buffer = its owned rows + its failure word
-__global__ void k_gather_pack(const double *w, const int *idx, int cnt, const int *err, double *out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cnt - 1) { const int r = idx[i]; out[i] = r >= 0 ? w[r] : 0.0; }
-  else if (i == cnt - 1) out[i] = err[0] != INT_MAX ? (double)err[0] : 0.0;
-}
-__global__ void k_gather_unpack(const double *recv, const int *idx, int cnt, long long total, double *w, double *errs) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= total) return;
-  const int i = (int)(j % cnt);
-  if (i == cnt - 1) { errs[j / cnt] = recv[j]; return; }
-  const int r = idx[j];
-  if (r >= 0) w[r] = recv[j];
-}
-__global__ void k_pack_w(const double *w, const unsigned char *mask, long long n, const int *err, int rank, int world, double *buf) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) buf[i] = mask[i] ? w[i] : 0.0;
-  if (i < world) buf[n + i] = (i == rank && err[0] != INT_MAX) ? (double)err[0] : 0.0;
-}
 
 // levels [g_lo, g_hi); `st` / `errflag`: the launch stream and failure word (st_factor_begin: the second stream, d_err2)
 static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, int g_hi = INT_MAX, hipStream_t st = nullptr, int *errflag = nullptr) {
@@ -4423,9 +1394,6 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
   return ST_OK;
 }
 
-__global__ void k_merge_err(int *err, const int *err2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0 && err2[0] < err[0]) err[0] = err2[0];
-}
 
 // Phase A of the top levels ahead of time, on the second stream: call before the sweep with the theta st_factor /
 // st_factor_local will be given next for the same slot.  A no-op when the tree does not qualify (or SPAMTREE_ASYNC_TOP=0).
@@ -5298,3 +2266,4 @@ extern "C" int st_summary_get(st_handle h, double *w_mean, double *yhat_mean, in
   if (yhat_mean) { int rc = download_rows(h, h->d_sum_yhat.p, yhat_mean); if (rc) return rc; for (long long i = 0; i < h->n_all; ++i) yhat_mean[i] *= inv; }
   return ST_OK;
 }
+
