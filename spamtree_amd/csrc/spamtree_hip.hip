@@ -1026,8 +1026,10 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   CCHK(h->d_B.alloc((size_t)pb->p * pb->q));
   CCHK(h->d_tsq.alloc(QMAX));
   for (int s = 0; s < 2; ++s) {
-    CCHK(h->d_panels[s].alloc(h->panel_total + 2));   // + 2: a 16-byte LDS-DMA piece may read one double past a row
-    CCHK(hipMemset(h->d_panels[s].p, 0, (h->panel_total + 2) * sizeof(double)));
+    // + 128: k_factor_lchain stages chain rows in whole 128-double LDS-DMA pieces and may read up to 127 doubles past a row's
+    // end (the other kernels: one double, an odd row's 16-byte piece); the padding is zeroed with the arena
+    CCHK(h->d_panels[s].alloc(h->panel_total + 128));
+    CCHK(hipMemset(h->d_panels[s].p, 0, (h->panel_total + 128) * sizeof(double)));
     CCHK(h->d_logdet[s].alloc(nb)); CCHK(h->d_loglik[s].alloc(nb));
     CCHK(hipMemset(h->d_logdet[s].p, 0, nb * sizeof(double)));
     CCHK(hipMemset(h->d_loglik[s].p, 0, nb * sizeof(double)));
@@ -1655,8 +1657,9 @@ extern "C" int st_sample_w_loglik_begin(st_handle h, const double *z, uint64_t s
   if (h->world > 1 || h->comm) {
     h->c_ll = 0.0;
     h->c_rc = st_sample_w_loglik(h, z, seed, iter, slot, &h->c_ll);
+    if (h->c_rc < 0) return h->c_rc;   // a HIP / RCCL / usage error: nothing is pending, the caller must not call _end
     h->c_pending = true;
-    return h->c_rc < 0 ? h->c_rc : ST_OK;
+    return ST_OK;
   }
   int rc = st_sample_w_local(h, z, seed, iter);
   if (rc) return rc;

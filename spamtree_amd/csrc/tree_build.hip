@@ -3,6 +3,7 @@
 // (spamtree_amd/topology.py), so contraction into FMAs is off for the whole file.
 #pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
+#include <climits>
 
 #include <cstdint>
 #include <string>
@@ -82,7 +83,10 @@ __global__ void k_nearest(const double *tx, const double *ty, const int *tmv, co
   const int mv = qmv[i];
   const bool filter = margin_has[mv] != 0;
   const int cx = cell_of(x, G.x0, G.cw, G.gx), cy = cell_of(y, G.y0, G.ch, G.gy);
-  const double cmin = G.cw < G.ch ? G.cw : G.ch;
+  // along an axis with ONE cell nothing is ever unvisited, so only the other axis bounds the distance to unvisited cells
+  // (collinear targets -- a transect -- give such a grid: with min(cw, ch) ~ 1e-302 the early exit below never fired and
+  // every query walked all 4096 rings)
+  const double cmin = G.gy == 1 ? G.cw : (G.gx == 1 ? G.ch : (G.cw < G.ch ? G.cw : G.ch));
   double best = __builtin_inf();
   long long bi = -1;
   const int rmax = G.gx > G.gy ? G.gx : G.gy;
@@ -114,6 +118,7 @@ __global__ void k_nearest(const double *tx, const double *ty, const int *tmv, co
 
 extern "C" int st_tb_sort(const double *x, int64_t n, int32_t device, double *sorted_out) {
   if (!x || !sorted_out || n < 0) return ST_ERR_USAGE;
+  if (n > (int64_t)INT_MAX) { st_set_create_error("st_tb_sort: more than INT_MAX keys (hipCUB's item count is an int)"); return ST_ERR_USAGE; }
   if (n == 0) return ST_OK;
   if (hipSetDevice(device) != hipSuccess) return fail("no usable HIP device");
   Dev D;
@@ -171,8 +176,14 @@ extern "C" int st_tb_nearest(const double *tx, const double *ty, const int32_t *
   Grid G;
   const double wx = std::max(x1 - x0, 1e-300), wy = std::max(y1 - y0, 1e-300);
   const double cells = std::max(1.0, (double)nt / 2.0);
-  G.gx = (int)std::min(4096.0, std::max(1.0, std::floor(std::sqrt(cells * wx / wy))));
-  G.gy = (int)std::min(4096.0, std::max(1.0, std::floor(cells / G.gx)));
+  const bool flat_y = (y1 - y0) <= 1e-12 * (x1 - x0), flat_x = (x1 - x0) <= 1e-12 * (y1 - y0);   // all targets on one line (or one point)
+  if (flat_x && flat_y) { G.gx = 1; G.gy = 1; }
+  else if (flat_y) { G.gx = (int)std::min(4096.0, std::max(1.0, std::floor(cells))); G.gy = 1; }
+  else if (flat_x) { G.gy = (int)std::min(4096.0, std::max(1.0, std::floor(cells))); G.gx = 1; }
+  else {
+    G.gx = (int)std::min(4096.0, std::max(1.0, std::floor(std::sqrt(cells * wx / wy))));
+    G.gy = (int)std::min(4096.0, std::max(1.0, std::floor(cells / G.gx)));
+  }
   G.x0 = x0; G.y0 = y0; G.cw = wx / G.gx * (1.0 + 1e-12); G.ch = wy / G.gy * (1.0 + 1e-12);
   const long long ncell = (long long)G.gx * G.gy;
   Dev D;

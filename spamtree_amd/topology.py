@@ -116,17 +116,25 @@ def _nearest_rows(tc, tmv, qc, qmv, n_margins, same_margin, device):
         tsel = np.nonzero(tmv == vv)[0]
         if tsel.size == 0:
             tsel = np.arange(tc.shape[0])
-        k = int(min(9, tsel.size))
         tree = cKDTree(tc[tsel])
-        _, nn = tree.query(qc[qsel], k=k)
-        nn = nn.reshape(qsel.size, k)
-        # exact squared distances in the arithmetic the device uses, ties to the lowest target index
-        cand = tsel[nn]
-        dx = qc[qsel, 0][:, None] - tc[cand, 0]
-        dy = qc[qsel, 1][:, None] - tc[cand, 1]
-        d2 = dx * dx + dy * dy
-        best = d2.min(axis=1)
-        out[qsel] = np.where(d2 == best[:, None], cand, np.iinfo(np.int64).max).min(axis=1)
+        todo = np.arange(qsel.size)
+        k = int(min(9, tsel.size))
+        while todo.size:
+            _, nn = tree.query(qc[qsel[todo]], k=k)
+            nn = nn.reshape(todo.size, k)
+            # exact squared distances in the arithmetic the device uses, ties to the lowest target index
+            cand = tsel[nn]
+            dx = qc[qsel[todo], 0][:, None] - tc[cand, 0]
+            dy = qc[qsel[todo], 1][:, None] - tc[cand, 1]
+            d2 = dx * dx + dy * dy
+            best = d2.min(axis=1)
+            out[qsel[todo]] = np.where(d2 == best[:, None], cand, np.iinfo(np.int64).max).min(axis=1)
+            # the device compares ALL targets: a query whose k candidates all tie with the best may have more ties beyond them
+            # (co-located outcomes x equidistant grid neighbours: 12 ties with q = 3) -- ask for more until one is farther
+            if k >= tsel.size:
+                break
+            todo = todo[d2.max(axis=1) == best]
+            k = int(min(4 * k, tsel.size))
     return out
 
 

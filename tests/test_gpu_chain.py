@@ -95,3 +95,70 @@ def test_cpp_driver_with_top_levels_ahead_of_time(async_top, monkeypatch):
     assert relerr(got["tausq_mcmc"], ref["tausq_mcmc"]) < 1e-8 and relerr(got["beta_mcmc"], ref["beta_mcmc"]) < 1e-8
     for i in range(3):
         assert relerr(np.asarray(got["w_mcmc"][i]).reshape(-1), ref["w_mcmc"][i]) < 1e-8
+
+
+def test_deferred_sweep_protocol_failure_and_misuse():
+    """st_sample_w_loglik_begin / _end (the C++ driver's default).  A sweep that fails (negative tausq^-1: codes
+    10 / 11, spamtree_model.cpp:1056, 1135) surfaces from _end AFTER the proposal's st_factor has run in between; a second
+    _begin without _end is refused; the handle is usable afterwards and gives what the synchronous call gives."""
+    import ctypes as C
+    from tests.test_gpu_parity import hip_model
+    pb = make_problem(side=25, q=1, seed=21)
+    hm = hip_model(pb, tausq=0.2)
+    lib, h = hm.lib, hm.h
+    dp = C.POINTER(C.c_double)
+    th = np.ascontiguousarray(pb["theta"], dtype=np.float64)
+    assert hm.get_loglik_comps_w(0)
+    z = np.random.default_rng(0).standard_normal(pb["n"])
+    # reference: the synchronous pair (after one warm-up sweep: the first sweep after a factorisation also rebuilds the
+    # records' Gram parts and takes other kernels, equal to 1e-12 but not bit for bit)
+    ll_sync = C.c_double()
+    assert lib.st_sample_w_loglik(h, z.ctypes.data_as(dp), 0, 0, 0, C.byref(ll_sync)) == 0
+    hm.set_w(np.zeros(pb["n"]))
+    assert lib.st_sample_w_loglik(h, z.ctypes.data_as(dp), 0, 0, 0, C.byref(ll_sync)) == 0
+    w_sync = hm.get_w().copy()
+    # deferred: the same sweep from the same state, the proposal's phase A in between
+    hm.set_w(np.zeros(pb["n"]))
+    assert lib.st_sample_w_loglik_begin(h, z.ctypes.data_as(dp), 0, 0, 0) == 0
+    assert lib.st_sample_w_loglik_begin(h, z.ctypes.data_as(dp), 0, 0, 0) < 0                  # a second _begin without _end: usage error
+    ll_f = C.c_double()
+    assert lib.st_factor(h, 1, th.ctypes.data_as(dp), th.size, C.byref(ll_f)) == 0
+    ll_def = C.c_double()
+    assert lib.st_sample_w_loglik_end(h, C.byref(ll_def)) == 0
+    assert np.array_equal(hm.get_w(), w_sync) and ll_def.value == ll_sync.value
+    assert lib.st_sample_w_loglik_end(h, C.byref(ll_def)) < 0                                 # _end without _begin
+    # a failing sweep: negative tausq^-1 makes the posterior precision of every block indefinite
+    bad = np.array([-50.0])
+    assert lib.st_set_tausq_inv(h, bad.ctypes.data_as(dp)) == 0
+    assert lib.st_sample_w_loglik_begin(h, z.ctypes.data_as(dp), 0, 1, 0) == 0
+    assert lib.st_factor(h, 1, th.ctypes.data_as(dp), th.size, C.byref(ll_f)) == 0
+    assert lib.st_sample_w_loglik_end(h, C.byref(ll_def)) in (10, 11)
+    # the handle is not poisoned: restore tausq and w, the synchronous sweep reproduces the reference
+    good = np.array([1.0 / 0.2])
+    assert lib.st_set_tausq_inv(h, good.ctypes.data_as(dp)) == 0
+    hm.set_w(np.zeros(pb["n"]))
+    ll3 = C.c_double()
+    assert lib.st_sample_w_loglik(h, z.ctypes.data_as(dp), 0, 0, 0, C.byref(ll3)) == 0
+    assert np.array_equal(hm.get_w(), w_sync) and ll3.value == ll_sync.value
+    hm.close()
+
+
+def test_chain_with_and_without_deferred_sync_are_identical():
+    """SPAMTREE_DEFER_SYNC is read once per process, so the two settings run in subprocesses: same chain bit for bit."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from tests.util import make_problem\nfrom spamtree_amd import fit\n"
+            "pb = make_problem(side=25, q=1, seed=3, missing=0.1)\n"
+            "ch = fit.Chain(pb['y'], pb['X'], pb['Z'], pb['coords'], pb['mv_id'], pb['blocking'], pb['gix_block'], pb['res_is_ref'],"
+            " pb['parents'], pb['children'], False, pb['block_names'], pb['block_groups'], pb['indexing'], pb['bounds'], pb['theta'],"
+            " np.zeros(pb['p']), 0.1, 0.01 * np.eye(4), seed=5)\n"
+            "ch.step(40); st = ch.state()\n"
+            "print(repr((st['theta'].tolist(), st['tausq_inv'].tolist(), st['loglik'], float(np.sum(ch.get_w())))))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPAMTREE_DEFER_SYNC=flag), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]

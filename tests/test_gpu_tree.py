@@ -58,6 +58,41 @@ def test_device_nearest_matches_brute_force(grid):
     assert np.array_equal(tp._nearest_rows(tc, tmv, qc, qmv, 3, True, None), ref)      # the host path follows the same rule
 
 
+def test_device_nearest_many_ties_and_collinear_targets():
+    """(a) more exact ties than the host path's first candidate batch (12: four equidistant neighbours x three
+    co-located margins under the all-margins fallback) -- both paths pick the lowest index; (b) collinear targets (a transect):
+    the grid collapses to one row of cells and the ring walk must still stop early (the result is checked; the time bound is
+    what a 4096-ring walk per query would blow)."""
+    import time
+    g = np.stack(np.meshgrid(np.arange(9.0), np.arange(9.0), indexing="ij"), -1).reshape(-1, 2)
+    tc = np.tile(g, (3, 1)); tmv = np.repeat([0, 1, 2], g.shape[0])
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(tc.shape[0]); tc, tmv = tc[perm], tmv[perm]
+    qc = g[(g[:, 0] % 2 == 1) & (g[:, 1] % 2 == 1)] + 0.0
+    keep = ~((tc[:, None, :] == qc[None, :, :]).all(-1).any(1))            # the query points themselves are not targets
+    tc, tmv = tc[keep], tmv[keep]
+    qmv = np.full(qc.shape[0], 3)                                         # margin 3 has no target
+    d2 = ((qc[:, None, :] - tc[None, :, :]) ** 2).sum(-1)
+    ref = np.argmax(d2 == d2.min(axis=1)[:, None], axis=1)
+    assert (d2 == d2.min(axis=1)[:, None]).sum(axis=1).min() >= 12
+    assert np.array_equal(tp._nearest_rows(tc, tmv, qc, qmv, 4, True, 0), ref)
+    assert np.array_equal(tp._nearest_rows(tc, tmv, qc, qmv, 4, True, None), ref)
+    # (b) a transect: 200 000 targets on the line y = 0.3, 50 000 queries off it
+    tx = rng.uniform(size=200000); tc = np.stack([tx, np.full_like(tx, 0.3)], 1)
+    qc = rng.uniform(size=(50000, 2))
+    z = np.zeros(tc.shape[0], dtype=np.int64)
+    t0 = time.time()
+    got = tp._nearest_rows(tc, z, qc, np.zeros(qc.shape[0], dtype=np.int64), 1, True, 0)
+    dt = time.time() - t0
+    assert dt < 20.0, dt
+    for lo in range(0, 600, 100):      # brute force on a sample (rounding makes many d2 ties here: dy^2 swamps small dx^2 differences)
+        q = qc[lo:lo + 100]
+        dx = q[:, 0][:, None] - tc[:, 0][None, :]; dy = q[:, 1][:, None] - tc[:, 1][None, :]
+        d2 = dx * dx + dy * dy
+        ref = np.argmax(d2 == d2.min(axis=1)[:, None], axis=1)
+        assert np.array_equal(got[lo:lo + 100], ref)
+
+
 @pytest.mark.parametrize("case", [dict(side=25, q=1), dict(side=14, q=3, missing=0.2), dict(side=30, q=1, missing=0.1, cell_size=9, K=(3, 2)),
                                   dict(side=30, q=1, tree_depth=2), dict(side=36, q=1, missing=0.05, cell_size=16, random=True),
                                   dict(side=18, q=3, missing=0.25, cell_size=9, mvbias=1.5), dict(side=120, q=2, missing=0.3, random=True),

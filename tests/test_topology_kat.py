@@ -99,3 +99,23 @@ def test_mvbias_prefers_the_sparser_margin_for_the_upper_levels():
     assert share[1] > 2.0 * share[0] and share[1] > 0.5
     t0 = tp.prepare(y, coords, mv)                          # the default is mvbias = 0
     assert np.array_equal(t0.blocking, tp.prepare(y, coords, mv, mvbias=0.0).blocking)
+
+
+def test_nearest_row_more_exact_ties_than_the_first_candidate_batch():
+    """with q >= 3 co-located outcomes and the all-margins fallback (the query's margin has no target) a grid point
+    has 4 equidistant neighbours x 3 outcomes = 12 exact ties -- more than the 9 candidates the host path first asks the
+    k-d tree for.  The rule (lowest target index among ALL ties, what the device kernel does) must still hold."""
+    g = np.stack(np.meshgrid(np.arange(5.0), np.arange(5.0), indexing="ij"), -1).reshape(-1, 2)
+    centre = np.array([[2.0, 2.0]])
+    nb = g[np.abs(g - centre).sum(axis=1) == 1.0]                  # the 4 neighbours at distance 1
+    far = g[np.abs(g - centre).sum(axis=1) > 1.0]
+    rng = np.random.default_rng(0)
+    tc = np.concatenate([far, np.tile(nb, (3, 1))])                # neighbours of three margins, co-located
+    tmv = np.concatenate([rng.integers(0, 3, size=far.shape[0]), np.repeat([0, 1, 2], 4)])
+    perm = rng.permutation(tc.shape[0])
+    tc, tmv = tc[perm], tmv[perm]
+    tmv3 = tmv.copy()                                              # margin 3 is absent among the targets -> all margins compete
+    got = tp._nearest_rows(tc, tmv3, centre, np.array([3]), 4, True, None)
+    d2 = ((tc - centre) ** 2).sum(axis=1)
+    ties = np.nonzero(d2 == d2.min())[0]
+    assert ties.size == 12 and got[0] == ties.min()
