@@ -23,10 +23,19 @@ assert hm.get_loglik_comps_w(0)
 z = rng.standard_normal(wl["n"])
 
 
+_it = [0]
+
+
 def sweep():
+    """one sweep with device-generated normals (Philox stream of the iteration, as the C++ driver runs it): the round-2 version
+    uploaded 8 MB of host normals per sweep, +0.5 ms of PCIe time that is not part of a chain's sweep"""
     hm.synchronize()
+    _it[0] += 1
     t0 = time.perf_counter()
-    hm.deal_with_w(z)
+    if os.environ.get("REBUILD_SWEEP_HOST_Z") == "1":
+        hm.deal_with_w(z)
+    else:
+        hm.deal_with_w(None, seed=7, it=_it[0])
     hm.synchronize()
     return (time.perf_counter() - t0) * 1e3
 

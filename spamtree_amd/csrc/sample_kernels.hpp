@@ -56,7 +56,9 @@ struct SampleFastArgs {
   int do_gram;   // 0: the Gram parts of the records are still valid for this theta, rewrite only the vectors
   int no_fwd;    // limited_tree: nothing is forwarded from the children's records
   double tausq_inv[QMAX];
+  const long long *gdesc_all;   // k_gram_direct: descriptors of ALL groups (the children's are looked up by group id)
 };
+#define GRAM_DIRECT_MAXCH 4     // k_gram_direct: child groups per block
 
 #ifdef ST_DEFS_SAMPLE
 
@@ -851,6 +853,138 @@ __global__ __launch_bounds__(NT, 6) void k_gram(SampleFastArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_gram for the LAST reference level when its children (the leaf groups) keep no Gram records at all: what a leaf group's
+// record would have carried for ancestor t -- N_{c,t}' N_{c,t}, the Gram matrix of the child's own panel columns -- is formed
+// HERE from the child's panel rows instead of being written by the leaf level (655 MB at n = 1e6), read back (655 MB) and
+// summed.  The leaf level of a rebuild sweep is then the ordinary leaf sweep (k_sample_leaf, vectors only: 0.40 instead of
+// 0.80 ms).  Same arithmetic as the two-kernel route, so the records are bit-identical: per ancestor tile one MFMA chain over the
+// block's own rows, one chain per child over that child's rows (exactly what the child's k_gram did: zero-padded K-steps),
+// the children's results summed in child order from 0.0 and added to the own part.  The part FOR this block itself
+// (the children's N_{c,u}' N_{c,u}, which the sweep kernels read from the children's records) goes to the children's
+// record slots as before.  spamtree_model.cpp:1162, 1190-1192.
+__global__ __launch_bounds__(NT, 4) void k_gram_direct(SampleFastArgs A) {
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32];
+  __shared__ int s_bld[32];
+  __shared__ long long s_coff[64];
+  __shared__ long long s_gd[GD_MAXW];
+  __shared__ long long s_rowoff[32];                         // panel offset of the block's own row r
+  __shared__ long long s_crow[GRAM_DIRECT_MAXCH][32];        // ... of child c's row r
+  __shared__ int s_cM[GRAM_DIRECT_MAXCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const int M = B0.M, J = B0.nanc, P = B0.P, nch = B0.ndch;   // nch <= GRAM_DIRECT_MAXCH (host)
+  __syncthreads();
+  if (tid < 32) {
+    long long off = 0;
+    if (tid < M) {
+      const long long r = B0.row0 + tid;
+      int bi = 0;
+      while (bi + 1 < B0.nblk && r >= s_brow[bi + 1]) ++bi;
+      off = s_bpan[bi] + (r - s_brow[bi]) * s_bld[bi];
+    }
+    s_rowoff[tid] = off;
+  }
+  if (tid >= 64 && tid < 64 + 32 * GRAM_DIRECT_MAXCH) {   // the children's rows: their descriptors sit behind the record offsets
+    const int c = (tid - 64) >> 5, r = (tid - 64) & 31;
+    long long off = 0;
+    int Mc = 0;
+    if (c < nch) {
+      const long long cg = s_gd[8 + 4 * J + 3 * B0.nblk + B0.ndch + c];
+      const long long *g = A.gdesc_all + (size_t)cg * A.gd_stride;
+      Mc = (int)(g[2] & 0xffffffffLL);
+      const int Jc = (int)(g[3] & 0xffffffffLL), nb = (int)(g[3] >> 32);
+      if (r < Mc) {
+        const long long ra = g[0] + r;
+        const long long *q = g + 8 + 4 * Jc;
+        int bi = 0;
+        while (bi + 1 < nb && ra >= q[3 * (bi + 1) + 1]) ++bi;
+        off = q[3 * bi] + (ra - q[3 * bi + 1]) * q[3 * bi + 2];
+      }
+    }
+    s_crow[c][r] = off;
+    if (r == 0) s_cM[c] = Mc;
+  }
+  __syncthreads();
+  const int nsteps = (M + 3) >> 2;          // <= 8
+  double *rec = A.acc + B0.acc_off;
+  // a wave owns one 16-row HALF of one ancestor's Gram matrix (tiles (it, 0) and (it, 1)): the two 16-column halves of a row
+  // set are loaded once per item and feed both chains -- half the operand loads of k_gram's one-tile-per-wave mapping, which
+  // at 53 rows per ancestor (own + children) is what bound this kernel, and few enough registers for four workgroups per CU
+  for (int u = wid; u < (J + 1) * 2; u += NT / 64) {
+    const int t = u >> 1, it = u & 1;
+    const bool self = t == J;                // the part for this block itself: children only, their columns [P, P + M)
+    const int ma = self ? M : s_am[t], oa = self ? P : s_ao[t];
+    if (it * 16 >= ma) continue;
+    const bool wide = ma > 16;               // otherwise only tile (0, 0) exists
+    // one row set (the block's own rows, or one child's) through the two chains
+    auto chains = [&](const long long *rowoff, int Mr, d4 (&cq)[2]) __attribute__((always_inline)) {
+      const int ns = (Mr + 3) >> 2;
+      double b0[8], b1[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int r = 4 * st + l4;
+        const bool rok = st < ns && r < Mr;
+        const double *row = A.panels + rowoff[min(r, 31)] + oa + l15;
+        b0[st] = rok ? row[0] : 0.0;
+        b1[st] = (rok && wide) ? row[16] : 0.0;
+      }
+      cq[0] = (d4){0.0, 0.0, 0.0, 0.0}; cq[1] = cq[0];
+#pragma unroll
+      for (int st = 0; st < 8; ++st)
+        if (st < ns) {
+          const double ai = it ? b1[st] : b0[st];
+          cq[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b0[st], cq[0], 0, 0, 0);
+          if (wide) cq[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b1[st], cq[1], 0, 0, 0);
+        }
+    };
+    auto store = [&](double *out, const d4 (&v)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        if (jt > 0 && !wide) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
+          if (i < ma && j < ma) out[i * ma + j] = v[jt][r];
+        }
+      }
+    };
+    // the children first: chv = ((0 + v_0) + v_1) + ... in child order, v_c = the child's chain (+ its own empty children's sum),
+    // exactly the sum k_gram forms from the children's records (entries outside the ancestor's m are never stored: no masks)
+    d4 chv[2];
+    chv[0] = (d4){0.0, 0.0, 0.0, 0.0}; chv[1] = chv[0];
+    for (int cc = 0; cc < nch; ++cc) {
+      d4 cch[2];
+      chains(s_crow[cc], s_cM[cc], cch);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cch[q][r] += 0.0; chv[q][r] += cch[q][r]; }
+      if (self) store(A.acc + s_coff[cc] + B0.acc_len, cch);   // the child's own record slot for its parent
+    }
+    if (!self) {
+      d4 c[2];
+      chains(s_rowoff, M, c);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[q][r] += chv[q][r];
+      store(rec + s_aoff[t], c);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Phase B, fast path, sweeps that keep the cached Gram parts (do_gram == 0: every sweep between two accepted theta).
 // Same results as k_sample_mfma up to rounding, but the panel is never staged in LDS: it is read twice from global
 // memory (L2 / Infinity Cache the second time) with a thread mapping chosen per pass --
@@ -1331,6 +1465,7 @@ template <bool BIG, bool NOREF = false> __global__ void k_sample(SampleArgs A);
 __global__ void k_gram_big(GramBigArgs A);
 __global__ void k_sample_mfma(SampleFastArgs A);
 __global__ void k_gram(SampleFastArgs A);
+__global__ void k_gram_direct(SampleFastArgs A);
 __global__ void k_sample_lean(SampleFastArgs A);
 __global__ void k_sample_wave(SampleFastArgs A);
 __global__ void k_sample_leaf(SampleFastArgs A);

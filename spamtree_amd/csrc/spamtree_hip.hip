@@ -151,6 +151,7 @@ struct st_handle_s {
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   int sample_wave = 1;                        // reference blocks of <= 27 rows: one block per wave (SPAMTREE_SAMPLE_WAVE=0: k_sample_lean)
+  int gram_direct_level = -1;                 // >= 0: that (last reference) level forms its children's Gram parts itself: k_gram_direct
   int split_gram = 1;                         // sweeps that rebuild the Gram parts: k_gram + lean kernels (SPAMTREE_SPLIT_GRAM=0: k_sample_mfma)
   bool stats_valid = false;                   // d_stats matches the current w and XB
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
@@ -938,13 +939,16 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     int stride = 8;
     for (const Grp &G : h->grps) {
       const Blk &B0 = h->blks[G.blk0];
-      stride = std::max(stride, 8 + 4 * B0.nanc + 3 * G.nblk + std::min(B0.ndch, 64));
+      stride = std::max(stride, 8 + 4 * B0.nanc + 3 * G.nblk + 2 * std::min(B0.ndch, 64));   // children: record offset + group id
     }
     stride = (stride + 1) & ~1;
     if (stride > GD_MAXW) return fail_create(h, ST_ERR_UNSUPPORTED, "group descriptor too long");
     h->gd_stride = stride;
     h->gdesc.assign(std::max<size_t>(1, h->grps.size()) * (size_t)stride, 0);
     auto pack = [](long long lo, long long hi) { return (lo & 0xffffffffLL) | (hi << 32); };
+    std::vector<long long> blk2grp((size_t)nb, -1);   // the group that holds a block (its first block holds the group's record)
+    for (size_t g = 0; g < h->grps.size(); ++g)
+      for (int b = 0; b < h->grps[g].nblk; ++b) blk2grp[h->grps[g].blk0 + b] = (long long)g;
     for (size_t g = 0; g < h->grps.size(); ++g) {
       const Grp &G = h->grps[g];
       const Blk &B0 = h->blks[G.blk0];
@@ -966,6 +970,30 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         q[0] = Bb.panel_off; q[1] = Bb.row0; q[2] = Bb.ld;
       }
       for (int c = 0; c < nch; ++c) w[8 + 4 * B0.nanc + 3 * G.nblk + c] = h->blks[h->dch_idx[B0.dch_ptr + c]].acc_off;
+      for (int c = 0; c < nch; ++c) w[8 + 4 * B0.nanc + 3 * G.nblk + nch + c] = blk2grp[h->dch_idx[B0.dch_ptr + c]];   // k_gram_direct
+    }
+    // Gram parts of the last reference level straight from the leaf groups' panels (k_gram_direct): every block of that level
+    // has at most GRAM_DIRECT_MAXCH children, all of them column groups of the (non-reference) last level
+    h->gram_direct_level = -1;
+    {
+      const int gl = n_actual - 1, gp = n_actual - 2;
+      const char *e = getenv("SPAMTREE_GRAM_DIRECT");
+      if (!(e && e[0] == '0') && gp >= 0 && !h->limited && h->levels[gl].fast && !h->levels[gl].isref && h->levels[gp].fast && h->levels[gp].isref &&
+          h->levels[gl].maxM <= 32 && h->levels[gl].maxP <= 255) {
+        bool ok = true;
+        const LevelInfo &Lp = h->levels[gp], &Ll = h->levels[gl];
+        for (int k = 0; k < Lp.grp_count && ok; ++k) {
+          const Grp &G = h->grps[Lp.grp_first + k];
+          const Blk &B0 = h->blks[G.blk0];
+          if (G.nblk != 1 || B0.ndch > GRAM_DIRECT_MAXCH) ok = false;
+          for (int c = 0; c < B0.ndch && ok; ++c) {
+            const long long cg = blk2grp[h->dch_idx[B0.dch_ptr + c]];
+            if (cg < Ll.grp_first || cg >= Ll.grp_first + Ll.grp_count || h->grps[cg].M > 32) ok = false;
+          }
+        }
+        // ... and every leaf group's record is read by a block of that level only (its direct parent)
+        if (ok) h->gram_direct_level = gp;
+      }
     }
     CCHK(h->d_gdesc.upload(h->gdesc));
   }
@@ -1732,11 +1760,22 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         F.gdesc = h->d_gdesc.p + (size_t)(L.grp_first + L.gown_lo) * h->gd_stride; F.gd_stride = h->gd_stride;
         for (int j = 0; j < QMAX; ++j) F.tausq_inv[j] = h->tausq_inv[j];
         const bool lean_ok = h->sample_lean != 0 && !(!L.isref && L.maxP > 255);
+        F.gdesc_all = h->d_gdesc.p;
+        // does level `gq` take k_gram + the lean kernels on a rebuild sweep?  (the same test for the level itself, below)
+        auto splits = [&](int gq) {
+          const LevelInfo &Lq = h->levels[gq];
+          const bool lean_q = h->sample_lean != 0 && !(!Lq.isref && Lq.maxP > 255);
+          return Lq.fast && lean_q && h->split_gram && (h->split_gram == 2 || (Lq.isref && Lq.gown_n >= 32 * h->sm_count));
+        };
+        // the leaf level of a rebuild sweep writes NO Gram parts when its parents form them from the leaf panels (k_gram_direct)
+        const bool direct_parent = F.do_gram && h->gram_direct_level == g && splits(g) && h->levels[g + 1].gown_n > 0;
+        if (F.do_gram && lean_ok && g == h->gram_direct_level + 1 && h->gram_direct_level >= 0 && splits(g - 1) && h->levels[g - 1].gown_n > 0) F.do_gram = 0;
         // the theta-only Gram parts on their own (k_gram), then the lean sweep kernels: pays on big reference levels (n = 1e6,
         // level 7: 0.84 -> 0.72 ms averaged over a run's sweeps), loses on leaf levels and on smaller reference levels, where
         // the staged Gram of k_sample_mfma is cheaper (SPAMTREE_SPLIT_GRAM=2: every level; records identical either way)
         if (F.do_gram && lean_ok && h->split_gram && (h->split_gram == 2 || (L.isref && L.gown_n >= 32 * h->sm_count))) {
-          hipLaunchKernelGGL(k_gram, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
+          if (direct_parent) hipLaunchKernelGGL(k_gram_direct, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
+          else hipLaunchKernelGGL(k_gram, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
           F.do_gram = 0;
         }
         if (F.do_gram || !lean_ok) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);

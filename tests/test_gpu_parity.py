@@ -238,6 +238,39 @@ def test_wave_sample_kernel_matches_lean_kernel_and_oracle(case, monkeypatch):
     assert relerr(ws[0][om.na_ix_all], om.w[om.na_ix_all]) <= REL
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[6], CASES[7], CASES[9]])
+def test_direct_gram_of_the_last_reference_level_is_bit_identical(case, monkeypatch):
+    """Round 3: on a rebuild sweep the leaf level writes no Gram parts; its parents form them from the leaf groups' panels
+    (k_gram_direct) instead of summing the children's records (k_gram).  Same arithmetic in the same order: the draws of
+    sweeps after a factorisation and after an accepted theta must be IDENTICAL to the record route (SPAMTREE_GRAM_DIRECT=0).
+    SPAMTREE_SPLIT_GRAM=2 puts every level on the split route, as the big levels of n = 1e6 are by default."""
+    pb = make_problem(seed=53, **case)
+    rng = np.random.default_rng(6)
+    zs = [rng.standard_normal(pb["n"]) for _ in range(4)]
+    monkeypatch.setenv("SPAMTREE_SPLIT_GRAM", "2")
+    ws = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("SPAMTREE_GRAM_DIRECT", direct)
+        hm = hip_model(pb, tausq=0.2)
+        assert hm.get_loglik_comps_w(0)
+        out = []
+        for it, z in enumerate(zs):
+            if it == 2:      # an accepted proposal: the records are rebuilt again
+                hm.theta_update(1, pb["theta"] * 1.03)
+                assert hm.get_loglik_comps_w(1)
+                hm.accept_make_change()
+            hm.deal_with_w(z)
+            out.append(hm.get_w().copy())
+        ws.append(out)
+        hm.close()
+    for a, b in zip(*ws):
+        assert np.array_equal(a, b)
+    om = oracle_model(pb, tausq=0.2)
+    assert om.get_loglik_comps_w(om.param_data)
+    om.gibbs_sample_w(zs[0]); om.gibbs_sample_w(zs[1])
+    assert relerr(ws[0][1][om.na_ix_all], om.w[om.na_ix_all]) <= REL
+
+
 def test_cross_covariance_ag10_export():
     """man/CrossCovarianceAG10.Rd:72-93 inputs (q = 2) and a q = 3 parameter set, device vs oracle (itself pinned by mpmath)."""
     from oracle import spamtree_oracle as so
