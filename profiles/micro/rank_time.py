@@ -1,6 +1,7 @@
 """Diagnostic (not part of the product): what ONE rank of an N-GPU run computes per iteration, timed on a single GPU
 without the collectives (the exchanged buffers simply keep the other ranks' entries at zero): the fixed cost that bounds
-strong scaling.  Run on the GPU box:  python profiles/micro/rank_time.py [side]"""
+strong scaling.  Run on the GPU box:  python profiles/micro/rank_time.py [side] [q] [cell_size] [missing, e.g. 0.1,0.3,0.5]
+(config #3: 1000; #4: 577 3; #5: 1155 3 9 0.1,0.3,0.5).  SINGLE-GPU ESTIMATE of the per-rank compute: no multi-GPU run is behind it."""
 import ctypes as C
 import os
 import sys
@@ -14,7 +15,11 @@ from spamtree_amd.model import SpamTreeMV, _dp, _f64  # noqa: E402
 from spamtree_amd.synthetic import make_workload  # noqa: E402
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-wl = make_workload(side)
+q = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cell = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+missing = tuple(float(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else None
+wl = make_workload(side, q=q, cell_size=cell, missing=missing, device=0)
+print(f"workload: side {side} q {q} cell_size {cell} missing {missing}: n = {wl['n']}")
 rng = np.random.default_rng(0)
 for world in (1, 2, 4, 8):
     hm = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"], wl["res_is_ref"],
