@@ -463,6 +463,20 @@ def main():
     fence()
     prof_all = model.profile_get()
     lvl_ms, lvl_bytes, smp_ms, smp_bytes = model.profile_levels_all()   # per-level phase-A / phase-B times come from this pass too
+    # phase P (draws at the rows without an observation, spamtree_model.cpp:1234-1358; the reference runs it on every SAVED
+    # iteration, spamtree_fit.cpp:300-306): not part of the timed iteration, timed on its own when the workload has such rows
+    predict = None
+    n_na = int(np.sum(~np.isfinite(wl["y"])))
+    if n_na > 0 and native:
+        import ctypes as C
+        from spamtree_amd import _lib
+        lib = _lib.load()
+        for _ in range(4):
+            lib.st_predict(C.c_void_p(lib.stm_handle(chain.c)), 1)
+        pp = model.profile_get()["predict"]
+        predict = {"rows": n_na, "ms_per_call": round(pp[0] / max(1, pp[1]), 4), "calls": pp[1],
+                   "note": "st_predict on its own (HIP events), after the timed region; the leaf path of k_factor_quad where the prediction "
+                           "blocks are eligible, else the generic kernel"}
     model.profile(0)
     n_levels = max(1, len(lvl_ms))
     avg_launch_ms = fac_ms / max(1, fac_n)
@@ -604,6 +618,7 @@ def main():
                                               for b, m in zip(smp_bytes, smp_ms)],
                      "phase_ms_per_iter": {kk: round((prof[kk][0] / args.steps) if kk == "factor" else (v[0] / n_extra), 4)
                                            for kk, v in prof_all.items()},
+                     "predict": predict,
                      "phase_ms_note": "factor (and avg_launch_ms, achieved): one HIP-event pair around each phase A of the timed "
                                       "steps; by_level_ms and the other families: an untimed pass of "
                                       f"{n_extra} steps with every launch bracketed (event traffic costs 4-6 % of an iteration)"},

@@ -43,6 +43,9 @@ struct QuadArgs {
   int ldS;   // staged row stride: >= longest row + 24 zero-filled columns
   int wave_chol;   // the level's blocks have <= 27 rows: one-wave register elimination (a property of the LEVEL, so that a
                    // unit's arithmetic does not depend on which units share its workgroup)
+  int predict;     // leaf instantiations: phase P (spamtree_model.cpp:1296-1326) -- draw w_j = H_j w_pa + sqrt(max(K_jj - H_j K_pa,j, 0)) z_j
+  const double *z; // ... from these normals (device order), into w_out; nothing else is written
+  double *w_out;
 };
 
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
@@ -483,35 +486,42 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
     dsum += __shfl_xor(dsum, 32, 64);
     const int jc = jt * 16 + l15;
     double rj = 0.0;
+    double dj = 1.0;
     if (jc < Mu) {
-      const double d = cov_entry(cp, s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc], s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc]) - dsum;
-      if (!(d > 0.0)) s_fail[u] = 1;
-      rj = 1.0 / sqrt(d);
+      dj = cov_entry(cp, s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc], s_colx[u][jc], s_coly[u][jc], s_colmv[u][jc]) - dsum;
+      if (!(dj > 0.0) && !A.predict) s_fail[u] = 1;
+      rj = 1.0 / sqrt(dj);
     }
-    {
-      // hv of column l15 sits in h_{l15 >> 2} of the lanes with l4 == (l15 & 3)
-      const int srcl = ((l15 & 3) << 4) | l15;
-      const double t0 = __shfl(h0, srcl, 64), t1 = __shfl(h1, srcl, 64), t2 = __shfl(h2, srcl, 64), t3 = __shfl(h3, srcl, 64);
-      const double hvc = (l15 >> 2) == 0 ? t0 : ((l15 >> 2) == 1 ? t1 : ((l15 >> 2) == 2 ? t2 : t3));
+    // hv of column l15 sits in h_{l15 >> 2} of the lanes with l4 == (l15 & 3)
+    const int srcl = ((l15 & 3) << 4) | l15;
+    const double t0 = __shfl(h0, srcl, 64), t1 = __shfl(h1, srcl, 64), t2 = __shfl(h2, srcl, 64), t3 = __shfl(h3, srcl, 64);
+    const double hvc = (l15 >> 2) == 0 ? t0 : ((l15 >> 2) == 1 ? t1 : ((l15 >> 2) == 2 ? t2 : t3));
+    if (A.predict) {   // (workgroup-uniform) phase P, spamtree_model.cpp:1306-1326: w_j = H_j w_pa + sqrt(max(K_jj - H_j K_pa,j, 0)) z_j;
+      // no panel, no scalars, no failure: prediction blocks own neither
+      if (jc < Mu && l4 == 0) {
+        const long long r = s_urow0[u] + jc;
+        A.w_out[r] = hvc + (dj > 0.0 ? sqrt(dj) : 0.0) * A.z[r];
+      }
+    } else {
       if (jc < Mu && l4 == 0) {
         const double e = rj * (s_colw[u][jc] - hvc);
         s_e2[u][jc] = e * e;
         s_lg[u][jc] = log(rj);
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = jt * 16 + l4 + 4 * r;
-      const double rr = __shfl(rj, l4 + 4 * r, 64);   // lane (0, column) holds that column's r
-      if (j < Mu) {
-        const int bi = s_colblk[u][j];
-        double *prow = A.panels + s_bpan[u][bi] + (size_t)(s_urow0[u] + j - s_brow[u][bi]) * s_bld[u][bi];
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 16 + l4 + 4 * r;
+        const double rr = __shfl(rj, l4 + 4 * r, 64);   // lane (0, column) holds that column's r
+        if (j < Mu) {
+          const int bi = s_colblk[u][j];
+          double *prow = A.panels + s_bpan[u][bi] + (size_t)(s_urow0[u] + j - s_brow[u][bi]) * s_bld[u][bi];
 #pragma unroll
-        for (int n = 0; n < NKT; ++n) {
-          const int k = n * 16 + l15;
-          if (k < Pu) prow[k] = -rr * tacc[n][r];
+          for (int n = 0; n < NKT; ++n) {
+            const int k = n * 16 + l15;
+            if (k < Pu) prow[k] = -rr * tacc[n][r];
+          }
+          if (l15 == 0) prow[Pu] = rr;
         }
-        if (l15 == 0) prow[Pu] = rr;
       }
     }
   } else {
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
       A.loglik_c[s_ublk0[u]] = (double)Mu * HL2PI - 0.5 * wc;
       if (s_fail[u]) atomicMin(A.errflag, s_level * 16 + (s_uJ[u] == 0 ? 1 : 2));
     }
-  } else {
+  } else if (!A.predict) {
     if (ttid < s_unblk[u]) {
       const int bi = ttid;
       double wc = 0.0, ldt = 0.0;

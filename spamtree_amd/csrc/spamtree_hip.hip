@@ -166,6 +166,8 @@ struct st_handle_s {
   ncclComm_t comm = nullptr;                  // native RCCL communicator (st_comm_init); null = exchanges are the caller's
   std::vector<LevelInfo> levels;
   LevelInfo pred_info;
+  int pred_grp_first = 0, pred_grp_count = 0, pred_quad_first = 0, pred_quad_count = 0, pred_nkx = 0;   // phase P on k_factor_quad's leaf path (pred_nkx = 0: generic kernel)
+  size_t pred_lds = 0;
   std::vector<double> xtx;
   std::vector<long long> n_obs_q;
 
@@ -872,6 +874,61 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     }
   }
   geometry(h->pred_info, h->pred_list, true);
+  // ---- phase P on the leaf path of k_factor_quad (prediction blocks are non-reference blocks behind a chain of reference
+  // blocks, exactly what a leaf level is: spamtree_model.cpp:1296-1326 is A7 + a draw): column groups of consecutive sibling
+  // prediction blocks (<= 32 columns) and quads of up to four groups that share all but the last ancestor.  Every rank predicts
+  // every block (as the generic kernel does: w is replicated).  Not eligible (long chains, wide blocks): the generic kernel.
+  h->pred_grp_first = (int)h->grps.size(); h->pred_grp_count = 0; h->pred_quad_first = (int)h->quads.size(); h->pred_quad_count = 0; h->pred_nkx = 0;
+  {
+    const LevelInfo &Lp = h->pred_info;
+    const char *e = getenv("SPAMTREE_PREDICT_FAST");
+    bool ok = !(e && e[0] == '0') && !h->force_generic && !h->pred_list.empty() && Lp.maxP > 0 && Lp.maxP <= 200 && Lp.maxMa <= 32 && Lp.maxM <= 32;
+    const std::vector<int> &list = h->pred_list;
+    size_t i = 0;
+    while (ok && i < list.size()) {
+      const Blk &B = h->blks[list[i]];
+      if (B.isref || B.nanc < 1) { ok = false; break; }
+      Grp G;
+      G.row0 = B.row0; G.blk0 = list[i]; G.nblk = 1; G.M = B.m; G.P = B.P;
+      const int lastp = h->anc_idx[B.anc_ptr + B.nanc - 1];
+      size_t j = i + 1;
+      while (j < list.size() && G.nblk < 32) {
+        const Blk &C = h->blks[list[j]];
+        const int lp = C.nanc ? h->anc_idx[C.anc_ptr + C.nanc - 1] : -1;
+        if (C.isref || lp != lastp || list[j] != list[j - 1] + 1 || G.M + C.m > 32 || C.row0 != G.row0 + G.M || C.P != B.P) break;
+        G.M += C.m; G.nblk += 1; ++j;
+      }
+      h->grps.push_back(G);
+      i = j;
+    }
+    if (!ok) h->grps.resize(h->pred_grp_first);
+    h->pred_grp_count = (int)h->grps.size() - h->pred_grp_first;
+    if (ok && h->pred_grp_count > 0) {
+      int k = 0;
+      while (k < h->pred_grp_count) {
+        const Grp &G0 = h->grps[h->pred_grp_first + k];
+        const Blk &B0 = h->blks[G0.blk0];
+        const int J = B0.nanc, Jc = J - 1;
+        Quad Qd;
+        Qd.g0 = k; Qd.nu = 1; Qd.Jc = Jc; Qd.Pc = 0;
+        for (int t = 0; t < Jc; ++t) Qd.Pc += h->blks[h->anc_idx[B0.anc_ptr + t]].m;
+        while (Qd.nu < h->quad_nu && k + Qd.nu < h->pred_grp_count) {
+          const Blk &B1 = h->blks[h->grps[h->pred_grp_first + k + Qd.nu].blk0];
+          if (B1.nanc != J) break;
+          bool same = true;
+          for (int t = 0; t < Jc && same; ++t) same = h->anc_idx[B1.anc_ptr + t] == h->anc_idx[B0.anc_ptr + t];
+          if (!same) break;
+          ++Qd.nu;
+        }
+        h->quads.push_back(Qd);
+        k += Qd.nu;
+      }
+      h->pred_quad_count = (int)h->quads.size() - h->pred_quad_first;
+      const int need = (Lp.maxP + 3) / 4;
+      h->pred_nkx = need <= 32 ? 32 : (need <= 38 ? 38 : (need <= 44 ? 44 : 50));
+      h->pred_lds = ((size_t)h->quad_nu * 16 * quad_lds_stride(h->pred_nkx) + quad_lds_stride(h->pred_nkx) + (size_t)2 * h->quad_nu * QUAD_LEAF_KH * 64) * 8;
+    }
+  }
 
   // ---- row data in device order
   std::vector<double> cx(n), cy(n), y(n), X((size_t)n * pb->p);
@@ -1142,6 +1199,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       if (L.q_nkx == 0) continue;
       if (L.lds_quad + stat > 160 * 1024) L.q_nkx = 0;
     }
+    if (h->pred_nkx && h->pred_lds + stat > 160 * 1024) h->pred_nkx = 0;
 #define QATTR(NU_, NKX_, NKT_)                                                                                                       \
   (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
   (void)hipFuncSetAttribute((const void *)k_factor_quad<NU_, NKX_, NKT_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)stat); \
@@ -2001,6 +2059,27 @@ extern "C" int st_predict(st_handle h, int theta_changed) {
   int rc = make_covpar(h, h->theta[0].data(), (int)h->theta[0].size(), &cp);
   if (rc) return rc;
   const LevelInfo &L = h->pred_info;
+  if (h->pred_nkx > 0 && h->pred_quad_count > 0) {
+    QuadArgs F;
+    std::memset(&F, 0, sizeof(F));
+    F.blks = h->d_blks.p; F.anc_idx = h->d_anc.p; F.grps = h->d_grps.p + h->pred_grp_first;
+    F.quads = h->d_quads.p + h->pred_quad_first; F.nquad = h->pred_quad_count;
+    F.cx = h->d_cx.p; F.cy = h->d_cy.p; F.mv = h->d_mv.p; F.w = h->d_w.p; F.panels = h->d_panels[h->slot_map[0]].p;
+    F.logdet_c = nullptr; F.loglik_c = nullptr; F.errflag = h->d_err.p; F.ldS = quad_lds_stride(h->pred_nkx);
+    F.gdesc = h->d_gdesc.p + (size_t)h->pred_grp_first * h->gd_stride; F.gd_stride = h->gd_stride;
+    F.wave_chol = 1; F.predict = 1; F.z = h->d_z.p; F.w_out = h->d_w.p;
+    {
+      ProfScope ps(h, 6);
+      const dim3 grid(h->pred_quad_count), blk(128 * 4);
+      if (h->pred_nkx == 32) hipLaunchKernelGGL((k_factor_quad<4, 32, 8, false, true>), grid, blk, h->pred_lds, h->stream, F, cp);
+      else if (h->pred_nkx == 38) hipLaunchKernelGGL((k_factor_quad<4, 38, 10, false, true>), grid, blk, h->pred_lds, h->stream, F, cp);
+      else if (h->pred_nkx == 44) hipLaunchKernelGGL((k_factor_quad<4, 44, 11, false, true>), grid, blk, h->pred_lds, h->stream, F, cp);
+      else hipLaunchKernelGGL((k_factor_quad<4, 50, 13, false, true>), grid, blk, h->pred_lds, h->stream, F, cp);
+    }
+    HCHK(h, hipGetLastError());
+    HCHK(h, hipStreamSynchronize(h->stream));
+    return ST_OK;
+  }
   FactorArgs A;
   std::memset(&A, 0, sizeof(A));
   A.blks = h->d_blks.p; A.anc_idx = h->d_anc.p; A.list = h->d_pred.p; A.nlist = (int)h->pred_list.size();
