@@ -459,10 +459,16 @@ def main():
     # phase breakdown of the other kernel families: a short untimed pass with every launch bracketed by events
     n_extra = max(1, min(10, args.steps))
     model.profile(1)
+    if native:      # every level of phase A on the launch stream for this pass (under the sweep, on the second stream, the top
+        from spamtree_amd import _lib as _l      # levels' launch times would not be their own)
+        import ctypes as _C
+        _l.load().st_factor_ahead_enable(_C.c_void_p(_l.load().stm_handle(chain.c)), 0)
     chain.step(n_extra)
     fence()
     prof_all = model.profile_get()
     lvl_ms, lvl_bytes, smp_ms, smp_bytes = model.profile_levels_all()   # per-level phase-A / phase-B times come from this pass too
+    if native:
+        _l.load().st_factor_ahead_enable(_C.c_void_p(_l.load().stm_handle(chain.c)), 1)
     # phase P (draws at the rows without an observation, spamtree_model.cpp:1234-1358; the reference runs it on every SAVED
     # iteration, spamtree_fit.cpp:300-306): not part of the timed iteration, timed on its own when the workload has such rows
     predict = None

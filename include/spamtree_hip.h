@@ -100,6 +100,9 @@ int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *lo
  * st_get_comps, st_loglik_w(1), st_mg_pack_comps) are ordered behind the launches in flight. */
 int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta);
 int st_factor_ahead_levels(st_handle h);   /* how many leading levels st_factor_begin runs ahead (0: none) */
+/* measurement only: 0 switches the ahead-of-time path off (st_factor_begin becomes a no-op, every level runs inside
+ * st_factor on the launch stream), 1 back on.  Results are identical either way. */
+int st_factor_ahead_enable(st_handle h, int enable);
 
 /* ---- accept_make_change (spamtree_model.cpp:1432-1435): swap the two cache slots */
 int st_swap(st_handle h);

@@ -21,7 +21,10 @@ NAMES = {0: "topology+coords", 1: "covariance", 2: "private ancestor step", 3: "
          12: "Ri out + e2", 13: "scalars"}
 
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-wl = make_workload(side)
+q = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cell = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+missing = tuple(float(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else None
+wl = make_workload(side, q=q, cell_size=cell, missing=missing, device=0)
 hm = SpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"], wl["res_is_ref"],
                 wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"], wl["indexing"],
                 np.zeros(wl["n"]), np.zeros(wl["p"]), wl["theta"], 10.0, device=0)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "st_get_block": (C.c_int, [H, C.c_int, C.c_int64, c_dp, c_dp]),
     "st_get_comps": (C.c_int, [H, C.c_int, c_dp, c_dp]),
     "st_algorithmic_bytes": (C.c_int, [H, c_dp, c_dp]),
+    "st_factor_ahead_enable": (C.c_int, [H, C.c_int]),
     "st_probe_peaks": (C.c_int, [C.c_int, C.c_int64, C.c_int, c_dp]),
     "st_profile_enable": (C.c_int, [H, C.c_int]),
     "st_profile_get": (C.c_int, [H, c_dp, c_ip]),

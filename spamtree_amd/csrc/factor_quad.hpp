@@ -100,6 +100,10 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   __shared__ double s_sx[PMAX], s_sy[PMAX], s_wpa[PMAX];
   __shared__ int s_smv[PMAX];
   __shared__ double s_exp2[64];         // 2^(j/64): cov_exp_tab
+  // multivariate covariance: the per-outcome-pair constants (rate, amp, amp2 of every pair, phi of every outcome).  Indexed per
+  // lane out of the kernel arguments they are GLOBAL loads -- three or four dependent round trips per entry; the covariance
+  // pass was 21-24 % of a quad's life at config #5 (stamps) -- so they live in LDS
+  __shared__ double s_cvr[QMAX * QMAX], s_cva[QMAX * QMAX], s_cva2[QMAX * QMAX], s_cvp[QMAX];
   __shared__ int s_rlen[PMAX];          // chain row c: its length (entries up to and including its own ancestor's rows) ...
   __shared__ long long s_rsrc[PMAX];    // ... and where it starts in the panel arena
 
@@ -129,6 +133,11 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
   }
   for (int k = tid; k < ldS; k += NTQ) zrow[k] = 0.0;
   if (tid < 64) s_exp2[tid] = EXP2_64[tid];
+  if (cp.q > 1 && tid >= 64 && tid < 64 + QMAX * QMAX) {
+    const int e = tid - 64;
+    s_cvr[e] = cp.rate[e]; s_cva[e] = cp.amp[e]; s_cva2[e] = cp.amp2[e];
+    if (e < QMAX) s_cvp[e] = cp.phi[e];
+  }
   __syncthreads();
   if (tid < NU) {
     int M = 0, P = 0, blk0 = 0, nblk = 0, isref = 0, J = 0, pm = 0;
@@ -282,19 +291,24 @@ __global__ __launch_bounds__(128 * NU, 2) void k_factor_quad(QuadArgs A, CovPar 
             kb[i * 64] = (cok && k < Pu) ? v : 0.0;
           }
         } else {
+          const int qn = cp.q;
 #pragma unroll 1
           for (int i = 0; i < KH; ++i) {
             const int k = 4 * (st0 + i) + l4;
-            double v = 0.0;
-            if (cok && k < Pu) {
-              double ax, ay; int av;
-              ax = s_sx[min(k, PMAX - 1)]; ay = s_sy[min(k, PMAX - 1)]; av = s_smv[min(k, PMAX - 1)];
-              if constexpr (!ISREF) {
-                if (k >= Pc) { ax = s_px[u][k - Pc]; ay = s_py[u][k - Pc]; av = s_pmv[u][k - Pc]; }
-              }
-              v = cov_entry_tab(cp, s_exp2, ax, ay, av, mx, my, mvj);
+            // branch-free: every lane evaluates both exponentials (amp2 is zero for pairs of different outcomes; within a wave the
+            // outcomes are mixed, so a branch on it made every wave walk both sides anyway), selects on the addresses
+            const double *pxs = &s_sx[min(k, PMAX - 1)], *pys = &s_sy[min(k, PMAX - 1)];
+            const int *pvs = &s_smv[min(k, PMAX - 1)];
+            if constexpr (!ISREF) {
+              if (k >= Pc) { pxs = &s_px[u][(k - Pc) & 31]; pys = &s_py[u][(k - Pc) & 31]; pvs = &s_pmv[u][(k - Pc) & 31]; }
             }
-            kb[i * 64] = v;
+            const int av = *pvs;
+            const double dx = *pxs - mx, dy = *pys - my;
+            const double hd = cov_sqrt(dx * dx + dy * dy);
+            const int ij = av * qn + mvj;
+            double v = s_cva[ij] * cov_exp_tab(-s_cvr[ij] * hd, s_exp2);
+            v = fma(s_cva2[ij], cov_exp_tab(-s_cvp[av] * hd, s_exp2), v);
+            kb[i * 64] = (cok && k < Pu) ? v : 0.0;
           }
         }
 #pragma unroll

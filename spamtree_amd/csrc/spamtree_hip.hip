@@ -135,7 +135,7 @@ struct st_handle_s {
   hipEvent_t ev_top = nullptr, ev_main = nullptr;
   DevBuf<int> d_err2, d_toplist;
   int n_toplist = 0, g_top = 0;
-  bool async_top = false, top_pending = false, prof_suspend = false;
+  bool async_top = false, top_pending = false, prof_suspend = false, async_top_off = false;
   hipEvent_t ev_stats = nullptr;
   bool stats_on_stream2 = false;   // the statistics kernels of the current (w, XB) are in flight on the second stream
   bool stats_prefetched = false;   // ... and their results follow them to pin[20 ..] on that stream
@@ -1485,10 +1485,17 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
 
 // Phase A of the top levels ahead of time, on the second stream: call before the sweep with the theta st_factor /
 // st_factor_local will be given next for the same slot.  A no-op when the tree does not qualify (or SPAMTREE_ASYNC_TOP=0).
-extern "C" int st_factor_ahead_levels(st_handle h) { return (h && h->async_top) ? h->g_top : 0; }
+extern "C" int st_factor_ahead_levels(st_handle h) { return (h && h->async_top && !h->async_top_off) ? h->g_top : 0; }
+// measurement: switch the ahead-of-time path off / on at run time (bench.py's per-level pass runs every level of phase A back
+// to back on ONE stream; on the second stream, under the sweep, the top levels' launch times are not their own)
+extern "C" int st_factor_ahead_enable(st_handle h, int enable) {
+  if (!h) return ST_ERR_USAGE;
+  h->async_top_off = !enable;
+  return ST_OK;
+}
 extern "C" int st_factor_begin(st_handle h, int slot, const double *theta, int ntheta) {
   if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
-  if (!h->async_top) return ST_OK;
+  if (!h->async_top || h->async_top_off) return ST_OK;
   HCHK(h, hipSetDevice(h->device));
   CovPar cp;
   int rc = make_covpar(h, theta, ntheta, &cp);
