@@ -1457,6 +1457,128 @@ __global__ __launch_bounds__(NT, 5) void k_sample_leaf(SampleFastArgs A) {
   if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 11);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_sample_leaf with SEGMENT-ALIGNED lanes (round 3).  k_sample_leaf maps lanes to consecutive chain columns, so the
+// per-ancestor segment sums of a row -- eight of them at n = 1e6 -- are eight masked 64-lane reductions (about 25
+// instructions each: 200 of a row's 260).  Here ancestor t owns a 32-lane HALF of register chunk t >> 1 (lane & 31 = its row,
+// blocks have at most 32 rows on this path), so one rotate-and-add butterfly inside the 16-lane rows (dpp_ror_add) plus the four
+// row sums through v_readlane give TWO ancestors' sums: 22 instructions per chunk, 88 per row for J = 8, no masks, no
+// ancestor search, and a lane's own segment sum stays in the lane for the vector records.  Same data, same result up to the
+// summation order inside a segment.  NCH = chunks = ceil(J / 2) <= NCH; spamtree_model.cpp:1091-1155, 1190-1203.
+template <int NCH>
+__global__ __launch_bounds__(NT, NCH <= 4 ? 4 : 3) void k_sample_leaf_seg(SampleFastArgs A) {
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ long long s_bpan[32], s_brow[32], s_rowoff[32];
+  __shared__ int s_bld[32];
+  __shared__ int s_fail;
+  __shared__ long long s_coff[64];
+  __shared__ int s_nch;
+  __shared__ long long s_gd[GD_MAXW];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *red = lds;                        // 4 x (64 NCH): per-wave column sums, slot = chunk * 64 + lane
+  double *tsq = red + 4 * 64 * NCH, *yx = tsq + 32, *zc = yx + 32;
+
+  int gidx = blockIdx.x;
+  {
+    const int per = A.ngrp >> 3;
+    if (gidx < per * 8) gidx = (gidx & 7) * per + (gidx >> 3);
+  }
+  for (int i = tid; i < A.gd_stride; i += NT) s_gd[i] = A.gdesc[(size_t)gidx * A.gd_stride + i];   // the group's descriptor: one round trip
+  __syncthreads();
+  const GdHead B0 = gd_unpack(s_gd, tid, s_am, s_ao, s_arow, nullptr, s_aoff, s_bpan, s_brow, s_bld, s_coff);
+  const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
+  const int M = G.M, P = G.P, J = B0.nanc;
+  if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
+  if (tid >= 32 && tid < 64) {
+    const int j = tid - 32;
+    double t_ = 0.0, y_ = 0.0, z_ = 0.0;
+    long long ro = 0;
+    if (j < M) {
+      const long long r = G.row0 + j;
+      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
+      int bi = 0;
+      const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
+      while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
+      ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
+    }
+    tsq[j] = t_; yx[j] = y_; zc[j] = z_; s_rowoff[j] = ro;
+  }
+  __syncthreads();
+  // this lane's columns: chunk c -> ancestor t = 2 c + (lane >> 5), its row i = lane & 31
+  const int hi = lane >> 5, li = lane & 31;
+  int kc[NCH];       // chain column, or -1
+  double wk[NCH], acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int t = 2 * c + hi;
+    const bool ok = t < J && li < s_am[min(t, MAXJ - 1)];
+    kc[c] = ok ? s_ao[t] + li : -1;
+    wk[c] = ok ? A.w[s_arow[t] + li] : 0.0;
+    acc[c] = 0.0;
+  }
+#pragma unroll 1
+  for (int b = 0; b < 2; ++b) {
+    double v[4][NCH], rjv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      const double *src = A.panels + s_rowoff[min(j, M - 1)];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) v[rr][c] = (j < M && kc[c] >= 0) ? src[kc[c]] : 0.0;
+      rjv[rr] = j < M ? src[P] : 0.0;          // the row's r_j (same address for every lane)
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = wid + 4 * (4 * b + rr);
+      if (j < M) {   // wave-uniform
+        double own[NCH];     // this lane's ancestor's segment sum, per chunk
+        double tvj = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (2 * c < J) {   // wave-uniform
+            double x = v[rr][c] * wk[c];
+            x = dpp_ror_add(x, 8); x = dpp_ror_add(x, 4); x = dpp_ror_add(x, 2); x = dpp_ror_add(x, 1);
+            const double r0 = readlane_f64(x, 0), r1 = readlane_f64(x, 16), r2 = readlane_f64(x, 32), r3 = readlane_f64(x, 48);
+            const double se = r0 + r1, so = r2 + r3;     // ancestors 2 c and 2 c + 1 (zero beyond J)
+            tvj += se; tvj += so;                        // tv = the segment sums in ancestor order
+            own[c] = hi ? so : se;
+          } else own[c] = 0.0;
+        }
+        const double rj = rjv[rr];
+        const double sig = rj * rj + tsq[j];
+        if (!(sig > 0.0) && lane == 0) s_fail = 1;
+        const double mu = -rj * tvj + tsq[j] * yx[j];
+        const double cc = 1.0 / sqrt(sig);
+        const double wj = cc * cc * mu + cc * zc[j];
+        if (lane == 0) A.w[G.row0 + j] = wj;
+        const double evj = rj * wj + tvj;
+        // this row's share of the vector records: -N[j][k] (ev_j - seg_t(k)[j])
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] -= v[rr][c] * (evj - own[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) red[(wid * NCH + c) * 64 + lane] = acc[c];
+  __syncthreads();
+  double *rec = A.acc + B0.acc_off;
+  for (int e = tid; e < 64 * NCH; e += NT) {
+    const int c = e >> 6, l = e & 63, t = 2 * c + (l >> 5), i = l & 31;
+    if (t < J && i < s_am[t]) {
+      const int ma = s_am[t];
+      double a = ((red[e] + red[64 * NCH + e]) + red[2 * 64 * NCH + e]) + red[3 * 64 * NCH + e];
+      for (int cc = 0; cc < s_nch; ++cc) a += A.acc[s_coff[cc] + s_aoff[t] + ma * ma + i];
+      rec[s_aoff[t] + ma * ma + i] = a;
+    }
+  }
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + 11);
+}
+template __global__ void k_sample_leaf_seg<4>(SampleFastArgs);
+template __global__ void k_sample_leaf_seg<6>(SampleFastArgs);
+
 template __global__ void k_sample<false, false>(SampleArgs);
 template __global__ void k_sample<true, false>(SampleArgs);
 template __global__ void k_sample<true, true>(SampleArgs);
@@ -1469,4 +1591,5 @@ __global__ void k_gram_direct(SampleFastArgs A);
 __global__ void k_sample_lean(SampleFastArgs A);
 __global__ void k_sample_wave(SampleFastArgs A);
 __global__ void k_sample_leaf(SampleFastArgs A);
+template <int NCH> __global__ void k_sample_leaf_seg(SampleFastArgs A);
 #endif

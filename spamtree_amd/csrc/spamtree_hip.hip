@@ -67,7 +67,7 @@ struct LevelInfo {
   bool fast = false;
   int grp_first = 0, grp_count = 0, Pm4 = 0, ldKV = 2, ldS = 2, SRm = 1, stage_dbl = 0;
   size_t lds_fast = 0;
-  int ldN = 2, Mr4 = 4, Mrows = 1, av_dbl = 224;
+  int ldN = 2, Mr4 = 4, Mrows = 1, av_dbl = 224, maxJ = 0;
   size_t lds_sfast = 0, lds_slean = 0;
   bool bigmfma = false;            // generic level whose phase A takes k_factor_bigmfma
   int wide_first = 0, wide_count = 0, wide_maxN = 0;   // sibling groups of this rank's run (k_factor_wide); count 0: not used
@@ -151,6 +151,7 @@ struct st_handle_s {
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   int sample_wave = 1;                        // reference blocks of <= 27 rows: one block per wave (SPAMTREE_SAMPLE_WAVE=0: k_sample_lean)
+  int leaf_seg = 1;                           // k_sample_leaf_seg (segment-aligned lanes) where eligible
   int gram_direct_level = -1;                 // >= 0: that (last reference) level forms its children's Gram parts itself: k_gram_direct
   int split_gram = 1;                         // sweeps that rebuild the Gram parts: k_gram + lean kernels (SPAMTREE_SPLIT_GRAM=0: k_sample_mfma)
   bool stats_valid = false;                   // d_stats matches the current w and XB
@@ -641,6 +642,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         int maxJ = 0;
         for (int b : list) maxJ = std::max(maxJ, h->blks[b].nanc);
         L.av_dbl = std::max(32 * maxJ, 224);
+        L.maxJ = maxJ;
         const size_t dbl = (size_t)maxM * L.ldN + 32 + (size_t)L.maxP + 32 + 6 * 32 + (size_t)L.av_dbl + 16 + (L.isref ? (size_t)maxM * CH_LD : 0) + 16;
         L.lds_sfast = dbl * 8 + 64 * 4 + 64;
         L.lds_slean = ((size_t)L.maxP + 32 + (size_t)L.av_dbl + 224 + 16 + 7 * 32 + (L.isref ? 2 * 32 * CH_LD : 0) + 16) * 8;
@@ -1180,6 +1182,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     const char *e = getenv("SPAMTREE_FACTOR_KERNEL");
     h->factor_gen = (e && e[0] == '1') ? 1 : 3;
     { const char *e2 = getenv("SPAMTREE_SAMPLE_LEAN"); h->sample_lean = (e2 && e2[0] == '0') ? 0 : 1; }
+    { const char *e2 = getenv("SPAMTREE_LEAF_SEG"); h->leaf_seg = (e2 && e2[0] == '0') ? 0 : 1; }
     { const char *e2 = getenv("SPAMTREE_SPLIT_GRAM"); h->split_gram = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }
     { const char *e2 = getenv("SPAMTREE_SAMPLE_WAVE"); h->sample_wave = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }   // 2: every eligible level (tests)
   }
@@ -1844,7 +1847,14 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
           F.do_gram = 0;
         }
         if (F.do_gram || !lean_ok) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
-        else if (!L.isref) hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
+        else if (!L.isref) {
+          // segment-aligned lanes where the level's chains have at most 12 ancestors of at most 32 rows (SPAMTREE_LEAF_SEG=0: the
+          // column-aligned kernel)
+          const int need = (L.maxJ + 1) / 2;
+          if (h->leaf_seg && need <= 4 && L.maxMa <= 32) hipLaunchKernelGGL((k_sample_leaf_seg<4>), dim3(L.gown_n), dim3(NT), ((size_t)4 * 64 * 4 + 3 * 32) * 8, h->stream, F);
+          else if (h->leaf_seg && need <= 6 && L.maxMa <= 32) hipLaunchKernelGGL((k_sample_leaf_seg<6>), dim3(L.gown_n), dim3(NT), ((size_t)4 * 64 * 6 + 3 * 32) * 8, h->stream, F);
+          else hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
+        }
         else if (h->sample_wave && L.maxM <= 27 && (h->sample_wave == 2 || L.gown_n >= 32 * h->sm_count)) {   // one block per wave: 10 % faster on a level
           // that keeps every CU busy for many rounds (n = 1e6, level 7: 0.48 -> 0.43 ms), slower on latency-bound small levels: gd | wv | seg | tv, ev | Ri, per wave
           const size_t per = (((size_t)h->gd_stride + L.maxP + 32 + L.av_dbl + 64 + (size_t)std::max(L.maxM, 1) * CH_LD + 1) & ~(size_t)1);
