@@ -57,6 +57,13 @@ struct SampleFastArgs {
   int no_fwd;    // limited_tree: nothing is forwarded from the children's records
   double tausq_inv[QMAX];
   const long long *gdesc_all;   // k_gram_direct: descriptors of ALL groups (the children's are looked up by group id)
+  // theta-only part of a reference block's posterior precision, S0 = Ri' Ri + the children's Gram parts for the block
+  // (spamtree_model.cpp:912, 1044-1051 without the tausq term): cached per accepted theta like the records' Gram parts (Q4).
+  // s0_mode 0: compute (as every sweep did before round 3); 1: compute and store; 2: load.  Stored and loaded values are the
+  // same bits, so the draws do not depend on the mode.
+  double *s0;
+  const long long *s0off;       // per block: offset into s0 (row stride m) or -1
+  int s0_mode;
 };
 #define GRAM_DIRECT_MAXCH 4     // k_gram_direct: child groups per block
 
@@ -1076,19 +1083,25 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
   }
   __syncthreads();
   if (refgrp) {
+    const long long so = (A.s0off && A.s0_mode) ? A.s0off[B0.blk0] : -1;
+    const bool s0_load = so >= 0 && A.s0_mode == 2;
     for (int idx = tid; idx < M * M; idx += NT) {
       const int i = idx / M, j = idx - i * M;
       double a = 0.0;
       if (j <= i) {
-        double ch[4];   // the children's records: four loads in flight, fixed summation order
-        for (int c0 = 0; c0 < s_nch; c0 += 4) {
+        if (s0_load) a = A.s0[so + idx];
+        else {
+          double ch[4];   // the children's records: four loads in flight, fixed summation order
+          for (int c0 = 0; c0 < s_nch; c0 += 4) {
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
-          if (c0 == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
+            for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + idx] : 0.0;
+            if (c0 == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
 #pragma unroll
-          for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+            for (int cc = 0; cc < 4; ++cc) a += ch[cc];
+          }
+          if (s_nch == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
+          if (so >= 0) A.s0[so + idx] = a;   // s0_mode 1
         }
-        if (s_nch == 0) for (int k = i; k < M; ++k) a += Rc[k * CH_LD + i] * Rc[k * CH_LD + j];
         if (i == j) a += tsq[i];
       }
       S[i * CH_LD + j] = a;
@@ -1265,21 +1278,35 @@ __global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
 #pragma unroll
   for (int j = 0; j < 27; ++j) a[j] = 0.0;
   double bv = 0.0;
-  for (int k = 0; k < M; ++k) {                      // Ri[k][i] = 0 for k < i: the leading terms add exact zeros
-    const double rk = Rc[k * CH_LD + li];
-    bv -= rk * tv[k];
+  const long long so = (A.s0off && A.s0_mode) ? A.s0off[slo(s_gd[6])] : -1;
+  if (so >= 0 && A.s0_mode == 2) {                   // (wave-uniform) the theta-only part of the row comes from the cache
+    const double *sp = A.s0 + so + (size_t)li * M;
 #pragma unroll
-    for (int j = 0; j < 27; ++j) a[j] += rk * Rc[k * CH_LD + j];
-  }
-  for (int c = 0; c < nch; ++c) {                    // the children's records, fixed order
-    const double *rc = A.acc + coff[c] + acc_len;
-    double ch[27];
+    for (int j = 0; j < 27; ++j) a[j] = (row && j <= lane) ? sp[j] : 0.0;
+    for (int k = 0; k < M; ++k) bv -= Rc[k * CH_LD + li] * tv[k];
+    for (int c = 0; c < nch; ++c) bv += row ? A.acc[coff[c] + acc_len + M * M + li] : 0.0;
+  } else {
+    for (int k = 0; k < M; ++k) {                      // Ri[k][i] = 0 for k < i: the leading terms add exact zeros
+      const double rk = Rc[k * CH_LD + li];
+      bv -= rk * tv[k];
 #pragma unroll
-    for (int j = 0; j < 27; ++j) ch[j] = (row && j <= lane) ? rc[li * M + j] : 0.0;
-    const double cv = row ? rc[M * M + li] : 0.0;
+      for (int j = 0; j < 27; ++j) a[j] += rk * Rc[k * CH_LD + j];
+    }
+    for (int c = 0; c < nch; ++c) {                    // the children's records, fixed order
+      const double *rc = A.acc + coff[c] + acc_len;
+      double ch[27];
 #pragma unroll
-    for (int j = 0; j < 27; ++j) a[j] += ch[j];
-    bv += cv;
+      for (int j = 0; j < 27; ++j) ch[j] = (row && j <= lane) ? rc[li * M + j] : 0.0;
+      const double cv = row ? rc[M * M + li] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 27; ++j) a[j] += ch[j];
+      bv += cv;
+    }
+    if (so >= 0 && row) {                              // s0_mode 1
+      double *sp = A.s0 + so + (size_t)li * M;
+#pragma unroll
+      for (int j = 0; j < 27; ++j) if (j <= lane) sp[j] = a[j];
+    }
   }
 #pragma unroll
   for (int j = 0; j < 27; ++j) {

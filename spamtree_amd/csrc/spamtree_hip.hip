@@ -158,6 +158,7 @@ struct st_handle_s {
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
   std::vector<double> host_stats;
   double *pin = nullptr;                      // 64 doubles of pinned host memory for the small device-to-host reads
+  std::vector<char> s0_valid;                 // per level: d_s0 holds the theta-only precision parts of the accepted theta (column-group levels)
   bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
   bool cache_gram = true;
   bool limited = false;               // limited_tree: single parents, marginal chain factors (k_marginal_invchol)
@@ -1064,7 +1065,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     size_t tot = 0;
     for (int g = 0; g < n_actual; ++g) {
       const LevelInfo &L = h->levels[g];
-      if (!L.big_sample || !L.isref) continue;
+      if (!L.isref || !(L.big_sample || L.fast)) continue;   // generic wide-block levels (round 2) and the column-group levels (round 3)
       for (int k = 0; k < L.count; ++k) {
         const int b = h->lvl_list[L.first + k];
         s0off[b] = (long long)tot;
@@ -1239,6 +1240,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   }
   (void)hipGetLastError();
 #undef CCHK
+  h->s0_valid.assign((size_t)std::max(n_actual, 1), 0);
   h->prof_level_ms.assign(2 * n_actual, 0.0);
   h->prof_level_n.assign(2 * n_actual, 0);
   *out = h;
@@ -1314,6 +1316,7 @@ extern "C" int st_swap(st_handle h) {
   std::swap(h->slot_map[0], h->slot_map[1]);
   std::swap(h->theta[0], h->theta[1]);
   h->gram_valid = false;
+  std::fill(h->s0_valid.begin(), h->s0_valid.end(), 0);
   return ST_OK;
 }
 extern "C" int st_synchronize(st_handle h) {
@@ -1544,7 +1547,7 @@ extern "C" int st_factor_local(st_handle h, int slot, const double *theta, int n
   int rc = make_covpar(h, theta, ntheta, &cp);
   if (rc) return rc;
   h->theta[slot].assign(theta, theta + ntheta);
-  if (slot == 0) h->gram_valid = false;
+  if (slot == 0) { h->gram_valid = false; std::fill(h->s0_valid.begin(), h->s0_valid.end(), 0); }
   rc = reset_err(h);
   if (rc) return rc;
   const int phys = h->slot_map[slot];
@@ -1845,6 +1848,13 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
           if (direct_parent) hipLaunchKernelGGL(k_gram_direct, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
           else hipLaunchKernelGGL(k_gram, dim3(L.gown_n), dim3(NT), 0, h->stream, F);
           F.do_gram = 0;
+        }
+        // reference levels on the lean kernels: the theta-only part of the posterior precision (Ri' Ri + the children's Gram parts)
+        // is stored by the first such sweep after the records were rebuilt and loaded by the following ones (same bits either way)
+        if (!(F.do_gram || !lean_ok) && L.isref) {
+          F.s0 = h->d_s0.p; F.s0off = h->d_s0off.p;
+          F.s0_mode = !h->cache_gram ? 0 : (h->s0_valid[g] ? 2 : 1);
+          if (h->cache_gram) h->s0_valid[g] = 1;
         }
         if (F.do_gram || !lean_ok) hipLaunchKernelGGL(k_sample_mfma, dim3(L.gown_n), dim3(NT), L.lds_sfast, h->stream, F);
         else if (!L.isref) {
