@@ -2,6 +2,7 @@
 #pragma once
 #include "st_device.hpp"
 
+// k_factor<BIG, MODE>, k_factor_bigmfma: one block per workgroup
 struct FactorArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -22,6 +23,7 @@ struct FactorArgs {
 
 #define MODE_FACTOR 0
 #define MODE_PREDICT 1
+// k_marginal_invchol (limited_tree): the marginal inverse Cholesky factors the children read as their chain
 struct MarginalArgs {
   const Blk *blks;
   const int *list;

@@ -2,6 +2,7 @@
 #pragma once
 #include "st_device.hpp"
 
+// k_factor_mfma: one column group per workgroup
 struct FastArgs {
   const Blk *blks;
   const int *anc_idx;

@@ -2,6 +2,7 @@
 #pragma once
 #include "st_device.hpp"
 
+// k_loglik: phase C, one block per workgroup (any size)
 struct LoglikArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -13,6 +14,7 @@ struct LoglikArgs {
   int maxP, maxM;
 };
 
+// k_loglik_grp: phase C, one column group per workgroup
 struct LoglikGrpArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -29,6 +31,7 @@ struct LoglikGrpArgs {
 
 #define SUM2_WG 64
 #define STATS_WG 1024
+// k_qtile: posterior quantiles of the saved draws (list_mean.cpp:62-137)
 struct QtArgs {
   const double *draws;
   long long n;

@@ -2,6 +2,7 @@
 #pragma once
 #include "st_device.hpp"
 
+// k_sample<BIG, NOREF>: the any-size kernels (one block per workgroup; BIG: intermediates in a global scratch slice)
 struct SampleArgs {
   const Blk *blks;
   const int *anc_idx;
@@ -27,6 +28,7 @@ struct SampleArgs {
   double tausq_inv[QMAX];
 };
 
+// k_gram_big: theta-only parts of the generic path's records + Ri' Ri on the matrix cores
 struct GramBigArgs {
   const Blk *blks;
   const int *anc_idx, *dch_idx;
@@ -39,6 +41,7 @@ struct GramBigArgs {
   int no_fwd;
 };
 
+// the column-group kernels: k_sample_mfma, k_gram, k_gram_direct, k_sample_lean, k_sample_wave, k_sample_leaf, k_sample_leaf_seg
 struct SampleFastArgs {
   const Blk *blks;
   const int *anc_idx, *dch_idx;
