@@ -72,7 +72,7 @@ typedef struct st_options {
                                   per accepted theta -- identical values
                                   bit 1: limited_tree = TRUE (spamtree_fit.cpp:20, spamtree_model.cpp:901-903, 1275-1278):
                                   parents(u) is the single parent of make_edges_limited (tree_dep.cpp:133-186), children(u)
-                                  the direct children, and Kxx_inv(u) = inv_sympd(K_uu); single GPU only                  */
+                                  the direct children, and Kxx_inv(u) = inv_sympd(K_uu); sharded like full trees since round 3                  */
 } st_options;
 
 /* ---- lifetime: SpamTreeMV::SpamTreeMV (spamtree_model.cpp:8-192) incl. init_indexing/init_finalize/init_model_data */
@@ -215,6 +215,8 @@ int st_set_stream(st_handle h, void *stream);              /* launch on the call
 int st_comm_unique_id(void *out, int32_t cap);
 int st_comm_init(st_handle h, const void *unique_id);
 int st_shard_plan(const st_problem *pb, int32_t world, int64_t *owner /* n_blocks */, int32_t *cut_level);
+/* the same with options (needed for limited_tree problems, whose single-parent lists only parse with reserved bit 1 set) */
+int st_shard_plan_opt(const st_problem *pb, const st_options *opt, int32_t world, int64_t *owner /* n_blocks */, int32_t *cut_level);
 int st_shard_info(st_handle h, int32_t *rank, int32_t *world, int32_t *cut_level, int64_t *owned_blocks, int64_t *owned_rows);
 int st_factor_local(st_handle h, int slot, const double *theta, int ntheta);
 int st_loglik_local(st_handle h, int slot);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "st_stream": (C.c_void_p, [H]),
     "st_set_stream": (C.c_int, [H, C.c_void_p]),
     "st_shard_plan": (C.c_int, [C.POINTER(StProblem), C.c_int32, c_ip, C.POINTER(C.c_int32)]),
+    "st_shard_plan_opt": (C.c_int, [C.POINTER(StProblem), C.POINTER(StOptions), C.c_int32, c_ip, C.POINTER(C.c_int32)]),
     "st_shard_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_ip, c_ip]),
     "st_factor_local": (C.c_int, [H, C.c_int, c_dp, C.c_int]),
     "st_loglik_local": (C.c_int, [H, C.c_int]),

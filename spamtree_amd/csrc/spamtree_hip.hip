@@ -320,6 +320,13 @@ extern "C" int st_shard_plan(const st_problem *pb, int32_t world, int64_t *owner
   st_handle dummy = nullptr;
   return create_impl(pb, &opt, &dummy, true, owner, cut_level);
 }
+// the same for a problem that needs options to be read at all (limited_tree: st_options.reserved bit 1); rank / device of `opt` are ignored
+extern "C" int st_shard_plan_opt(const st_problem *pb, const st_options *opt_in, int32_t world, int64_t *owner, int32_t *cut_level) {
+  st_options opt = {0, 1, 0, world, 0, 0};
+  if (opt_in) { opt.reference_quirks = opt_in->reference_quirks; opt.force_generic = opt_in->force_generic; opt.reserved = opt_in->reserved; }
+  st_handle dummy = nullptr;
+  return create_impl(pb, &opt, &dummy, true, owner, cut_level);
+}
 
 static int create_impl(const st_problem *pb, const st_options *opt, st_handle *out, bool plan_only, int64_t *owner_out, int32_t *cut_out) {
   if (!pb || !out) { g_create_error = "st_create: null argument"; return ST_ERR_USAGE; }
@@ -336,7 +343,6 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   h->force_generic = opt ? opt->force_generic : 0;
   h->cache_gram = !(opt && (opt->reserved & 1));
   h->limited = opt && (opt->reserved & 2);
-  if (h->limited && h->world > 1) return fail_create(h, ST_ERR_UNSUPPORTED, "limited_tree with world > 1");
   const long long n = pb->n_all, nb = pb->n_blocks;
   h->n_all = n; h->n_blocks = nb; h->q = pb->q; h->p = pb->p; h->d = pb->d; h->n_groups = pb->n_groups;
   for (int j = 0; j < QMAX; ++j) h->tausq_inv[j] = 1.0;
@@ -496,7 +502,12 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         if (B.level < cut) continue;
         int r = -1;
         if (B.level == cut) r = i;
-        else for (int t = 0; t < B.nanc; ++t) { const int a = h->anc_idx[B.anc_ptr + t]; if (h->blks[a].level == cut) r = a; }
+        else if (B.nanc > 0) {
+          // through the DIRECT parent (the last ancestor), whose own root is known already: device order sorts blocks by level.
+          // Works for make_edges' full ancestor lists and for make_edges_limited's single parents (tree_dep.cpp:133-186) alike
+          const int par = h->anc_idx[B.anc_ptr + B.nanc - 1];
+          r = h->blks[par].level == cut ? par : root_of[par];
+        }
         if (r < 0) return fail_create(h, ST_ERR_TOPOLOGY, "block below the cut level without an ancestor on it");
         root_of[i] = r;
         wsub[r] += (double)B.m * ((double)B.P * B.P + 1.0);

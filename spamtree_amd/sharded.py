@@ -24,13 +24,17 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
 
 
-def shard_plan(pb_struct, world):
+def shard_plan(pb_struct, world, limited_tree=False):
     """owner[u] (rank, or -1 = replicated) and the cut level, from the library's pure-host planner."""
     lib = _lib.load()
     nb = int(pb_struct.n_blocks)
     owner = np.zeros(nb, dtype=np.int64)
     cut = C.c_int32()
-    rc = lib.st_shard_plan(C.byref(pb_struct), int(world), owner.ctypes.data_as(_lib.c_ip), C.byref(cut))
+    if limited_tree:
+        opt = _lib.StOptions(0, 1, 0, int(world), 0, 2)
+        rc = lib.st_shard_plan_opt(C.byref(pb_struct), C.byref(opt), int(world), owner.ctypes.data_as(_lib.c_ip), C.byref(cut))
+    else:
+        rc = lib.st_shard_plan(C.byref(pb_struct), int(world), owner.ctypes.data_as(_lib.c_ip), C.byref(cut))
     if rc != 0:
         raise SpamTreeError(f"st_shard_plan failed ({rc}): {lib.st_last_error(None).decode()}")
     return owner, cut.value

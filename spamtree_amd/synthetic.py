@@ -37,7 +37,7 @@ def true_theta(q):
                            np.linspace(0.5, 1.5, k)])
 
 
-def make_workload(side, q=1, p=3, seed=2021, missing=None, cell_size=25, device=None):
+def make_workload(side, q=1, p=3, seed=2021, missing=None, cell_size=25, device=None, limited_tree=False):
     """Grid workload: X ~ N(0,1), beta = (-1, .5, 1), tausq = .1, a smooth synthetic latent field of variance ~2.3.
 
     missing: None or per-outcome drop probabilities (config #5 uses (0.1, 0.3, 0.5)).
@@ -57,7 +57,7 @@ def make_workload(side, q=1, p=3, seed=2021, missing=None, cell_size=25, device=
     if missing is not None:
         pr = np.asarray(missing, dtype=np.float64)[mv_id - 1]
         y = np.where(rng.uniform(size=n) < pr, np.nan, y)
-    topo = prepare(y, coords, mv_id, cell_size=cell_size, device=device)   # device: the row-parallel tree-building steps on the GPU
+    topo = prepare(y, coords, mv_id, cell_size=cell_size, device=device, limited_tree=limited_tree)   # device: the row-parallel tree-building steps on the GPU
     s = topo.sort_ix
     Z = np.zeros((n, q))
     Z[np.arange(n), topo.mv_id - 1] = 1.0

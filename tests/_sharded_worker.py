@@ -31,7 +31,7 @@ def plan_worker(rank, world, port, case, out_dir):
     keep = [_i64(pb["res_is_ref"]), _i64(pb["block_names"]), _i64(pb["block_groups"]), ip, ii, pp, pi, cp, ci]
     st = _lib.StProblem(pb["n"], 2, pb["q"], pb["p"], int(keep[0].size), int(keep[1].size), _dp(y), _dp(X), _dp(co), _ip(mv),
                         *[_ip(a) for a in keep])
-    owner, cut = shard_plan(st, world)
+    owner, cut = shard_plan(st, world, limited_tree=bool(case.get("limited_tree", False)))
     nb = owner.size
     levels = np.unique(pb["block_groups"])
     lev_of = np.searchsorted(levels, pb["block_groups"])
@@ -42,8 +42,10 @@ def plan_worker(rank, world, port, case, out_dir):
     assert np.all(owner[below] >= 0) and np.all(owner[below] < world)
     for u in range(nb):                                  # a block below the cut inherits its cut-level ancestor's rank
         if lev_of[u] > cut:
-            anc = [a for a in pb["parents"][u] if lev_of[a] == cut]
-            assert len(anc) == 1 and owner[anc[0]] == owner[u]
+            a = u                                        # walk the direct parents up to the cut level (full lists: the last entry;
+            while lev_of[a] > cut:                       # make_edges_limited's lists: the only one)
+                a = pb["parents"][a][-1]
+            assert lev_of[a] == cut and owner[a] == owner[u]
     if cut < levels.size:
         assert len(set(owner[below].tolist())) == world, "every rank owns at least one subtree"
     # ---- exchange: every rank masks a full oracle result to what it owns; the all-reduce restores it bit for bit
@@ -68,14 +70,14 @@ def plan_worker(rank, world, port, case, out_dir):
     dist.destroy_process_group()
 
 
-def gpu_worker(rank, world, port, side, q, out_dir, steps):
+def gpu_worker(rank, world, port, side, q, out_dir, steps, limited=False):
     """Needs a GPU: `world` processes share device 0 and one problem; results go to out_dir for the parent to compare."""
     dist = _init(rank, world, port)
     from spamtree_amd.sharded import ShardedSpamTreeMV
     from spamtree_amd.synthetic import make_workload
-    wl = make_workload(side, q=q)
+    wl = make_workload(side, q=q, limited_tree=limited)
     m = ShardedSpamTreeMV(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
-                          wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
+                          wl["res_is_ref"], wl["parents"], wl["children"], bool(limited), wl["block_names"], wl["block_groups"],
                           wl["indexing"], np.zeros(wl["n"]), np.array([-0.5, 0.2, 0.4]), wl["theta"], 1.0 / 0.15,
                           device=0, dist=dist if world > 1 else None, allreduce_w=(world == 3))   # both forms of the w exchange
     rng = np.random.default_rng(3)

@@ -53,3 +53,23 @@ def test_sharded_equals_single_process_bitwise(side, q, quad_min, env, tmp_path,
             assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["xty"], ref["xty"]) and np.array_equal(r["ssq"], ref["ssq"])
             rows += int(r["owned_rows"])
         assert 0 < rows <= ref["w"].size
+
+
+@pytest.mark.parametrize("side,q,quad_min", [(120, 1, None), (120, 1, "1"), (40, 2, None)])
+def test_limited_tree_sharded_equals_single_process_bitwise(side, q, quad_min, tmp_path, monkeypatch):
+    """limited_tree = TRUE (tree_dep.cpp:133-186: every block has ONE parent; spamtree_model.cpp:901-903, 1275-1278) on 2 and 3
+    ranks: ownership follows the direct-parent chain up to the cut level, the cut-level records go to their single parents in
+    the replicated top; every result equals the single-process run bit for bit (round 3; single GPU only before)."""
+    if quad_min:
+        monkeypatch.setenv("SPAMTREE_QUAD_MIN", quad_min)
+    import torch.multiprocessing as mp
+    from tests._sharded_worker import gpu_worker
+    for world in (1, 2, 3):
+        mp.spawn(gpu_worker, args=(world, free_port(), side, q, str(tmp_path), 2, True), nprocs=world, join=True)
+    ref = np.load(tmp_path / "res_1_0.npz")
+    for world in (2, 3):
+        for rank in range(world):
+            r = np.load(tmp_path / f"res_{world}_{rank}.npz")
+            for k in ["ll_A", "ll_A2", "err", "ll_C0", "ll_C1"]:
+                assert float(r[k]) == float(ref[k]), (world, rank, k)
+            assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["xty"], ref["xty"]) and np.array_equal(r["ssq"], ref["ssq"])

@@ -14,7 +14,8 @@ def free_port():
 
 
 @pytest.mark.parametrize("world,case", [(2, dict(side=25, q=1, seed=4, missing=0.1)), (3, dict(side=40, q=1, seed=5)),
-                                        (2, dict(side=14, q=3, seed=6))])
+                                        (2, dict(side=14, q=3, seed=6)),
+                                        (3, dict(side=40, q=1, seed=7, limited_tree=True))])   # make_edges_limited's single parents (round 3)
 def test_plan_and_exchange_under_gloo(world, case, tmp_path):
     import numpy as np
     import torch.multiprocessing as mp
