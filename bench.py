@@ -180,6 +180,8 @@ def workload_name(args, wl, n_blocks, n_levels, world):
     known = {(1000, 1, 25, ""): "config #3", (316, 1, 25, ""): "config #2", (577, 3, 25, ""): "config #4",
              (1155, 3, 9, "0.1,0.3,0.5"): "config #5"}
     tag = known.get((args.side, args.q, args.cell_size, args.missing), "custom")
+    if getattr(args, "limited_tree", False):
+        tag = "custom (limited_tree = TRUE)"
     cov = "univariate exponential covariance" if args.q == 1 else f"q={args.q} Apanasovich-Genton cross-covariance"
     miss = f", outcomes dropped with probabilities ({args.missing})" if args.missing else ""
     return (f"{tag}: n={wl['n']} rows ({args.side}^2 grid x q={args.q}) {cov}{miss}, tree cell_size={args.cell_size} K=(2,2), "
@@ -347,6 +349,7 @@ def main():
     ap.add_argument("--q", type=int, default=1)
     ap.add_argument("--cell-size", type=int, default=25, help="knots per cell (config #5: 9)")
     ap.add_argument("--missing", type=str, default="", help="per-outcome drop probabilities, e.g. 0.1,0.3,0.5 (config #5)")
+    ap.add_argument("--limited-tree", action="store_true", help="limited_tree = TRUE: single-parent edges (tree_dep.cpp:133-186); a timing of that variant, not a BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stationary-windows", type=int, default=12,
                     help="at most this many untimed 50-iteration windows after the timed region until one accepts >= 20 %% (0 = skip)")
@@ -384,7 +387,7 @@ def main():
 
     t_setup = time.time()
     missing = tuple(float(x) for x in args.missing.split(",")) if args.missing else None
-    wl = make_workload(args.side, q=args.q, cell_size=args.cell_size, missing=missing, device=local_rank)
+    wl = make_workload(args.side, q=args.q, cell_size=args.cell_size, missing=missing, device=local_rank, limited_tree=args.limited_tree)
     # N > 1: one problem shared by all ranks -- subtrees below a cut level are owned by one GPU, the top is replicated,
     # exchanges are RCCL all-reduces issued by the library on its own stream (include/spamtree_hip.h, multi-GPU section)
     k = wl["theta"].size
@@ -396,7 +399,7 @@ def main():
     if not args.external:
         try:
             chain = fit.Chain(wl["y"], wl["X"], wl["Z"], wl["coords"], wl["mv_id"], wl["blocking"], wl["gix_block"],
-                              wl["res_is_ref"], wl["parents"], wl["children"], False, wl["block_names"], wl["block_groups"],
+                              wl["res_is_ref"], wl["parents"], wl["children"], bool(args.limited_tree), wl["block_names"], wl["block_groups"],
                               wl["indexing"], wl["bounds"], wl["theta"], np.zeros(wl["p"]), 0.1, 0.01 * np.eye(k), seed=2021,
                               adapting=True, device=local_rank, rank=rank, world=world, defer_comm=True)
         except Exception as exc:      # noqa: BLE001  (N > 1 only: every rank must agree before falling back)

@@ -16,7 +16,7 @@
 //   Rm: LDS, row stride CH_LD, lower triangle valid; destroyed.   Bm: LDS, receives L^{-1} (lower triangle only; what lies
 //   above the diagonal is not written).  All 64 lanes of the wave must call; no barrier inside (single wave: LDS program order).
 #pragma once
-#ifdef ST_DEFS_FACTOR_QUAD
+#if defined(ST_DEFS_FACTOR_QUAD) || defined(ST_DEFS_FACTOR_GENERIC)
 
 template <int J>
 __device__ __forceinline__ void fmac_bcast(double &d, const double src, const double f) {

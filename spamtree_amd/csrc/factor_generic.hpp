@@ -73,6 +73,40 @@ __global__ __launch_bounds__(NT) void k_marginal_invchol(MarginalArgs A, CovPar 
   }
 }
 
+// The same for blocks of at most 27 rows, ONE BLOCK PER WAVE (round 3): the workgroup version above factorises with a
+// barrier per pivot and inverts with one thread per column -- 0.7 ms for the 21 845 reference blocks of n = 1e6, as much as
+// all the level kernels of a limited tree together; here a wave builds K_uu in its own LDS slice and runs the blocked
+// 16 + 11 elimination of chol_blocked.hpp (9.5 k cycles, no barrier anywhere).
+__global__ __launch_bounds__(NT) void k_marginal_invchol_wave(MarginalArgs A, CovPar cp) {
+  extern __shared__ double lds[];   // per wave: R (32 x CH_LD) | L^{-1} (32 x CH_LD)
+  __shared__ int s_failw[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *R = lds + (size_t)wid * 64 * CH_LD, *Li = R + 32 * CH_LD;
+  for (int li = blockIdx.x * (NT / 64) + wid; li < A.nlist; li += gridDim.x * (NT / 64)) {
+    const Blk B = A.blks[A.list[li]];
+    const int m = B.m;   // <= 27 (host)
+    if (lane == 0) s_failw[wid] = 0;
+    for (int e = lane; e < m * (m + 1) / 2; e += 64) {
+      int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+      while (i * (i + 1) / 2 > e) --i;
+      while ((i + 1) * (i + 2) / 2 <= e) ++i;
+      const int j = e - i * (i + 1) / 2;
+      const long long ri = B.row0 + i, rj = B.row0 + j;
+      R[i * CH_LD + j] = cov_entry(cp, A.cx[ri], A.cy[ri], A.mv[ri], A.cx[rj], A.cy[rj], A.mv[rj]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_chol_eliminate_blocked<11>(R, Li, m, &s_failw[wid], lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    double *out = A.panels + B.chain_off;
+    for (int idx = lane; idx < m * m; idx += 64) {
+      const int i = idx / m, j = idx - i * m;
+      out[idx] = (j <= i) ? Li[i * CH_LD + j] : 0.0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0 && s_failw[wid]) atomicMin(A.errflag, B.level * 16 + 2);   // errtype 2 (:919), reported at the block's level
+  }
+}
+
 template <bool BIG, int MODE>
 __global__ __launch_bounds__(NT) void k_factor(FactorArgs A, CovPar cp) {
   extern __shared__ double lds[];
@@ -262,5 +296,6 @@ template __global__ void k_factor<false, MODE_PREDICT>(FactorArgs, CovPar);
 template __global__ void k_factor<true, MODE_PREDICT>(FactorArgs, CovPar);
 #else   // host side: prototypes only (the kernels are compiled in their own translation unit)
 __global__ void k_marginal_invchol(MarginalArgs A, CovPar cp);
+__global__ void k_marginal_invchol_wave(MarginalArgs A, CovPar cp);
 template <bool BIG, int MODE> __global__ void k_factor(FactorArgs A, CovPar cp);
 #endif

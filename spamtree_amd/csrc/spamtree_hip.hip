@@ -1188,6 +1188,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   (void)hipFuncSetAttribute((const void *)k_sample_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_sample_wave, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute((const void *)k_marginal_invchol, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute((const void *)k_marginal_invchol_wave, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   {
     // phase A kernel for the column-group levels: 3 (default) = k_factor_quad where a level is eligible (big enough,
     // chains <= 200 rows, LDS fits) and k_factor_mfma elsewhere; 1 = k_factor_mfma everywhere
@@ -1429,7 +1430,10 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
     M.blks = h->d_blks.p; M.list = h->d_twin.p; M.nlist = (int)h->twin_list.size(); M.cx = h->d_cx.p; M.cy = h->d_cy.p; M.mv = h->d_mv.p;
     M.panels = h->d_panels[phys].p; M.errflag = errflag; M.maxM = h->twin_maxM;
     const size_t lds = (size_t)2 * h->twin_maxM * h->twin_maxM * sizeof(double);
-    hipLaunchKernelGGL(k_marginal_invchol, dim3(std::min(M.nlist, 8 * h->sm_count)), dim3(NT), lds, st, M, cp);
+    if (h->twin_maxM <= 27 && !h->force_generic)   // one block per wave, blocked DPP / MFMA elimination
+      hipLaunchKernelGGL(k_marginal_invchol_wave, dim3(std::min((M.nlist + NT / 64 - 1) / (NT / 64), 8 * h->sm_count)), dim3(NT),
+                         (size_t)(NT / 64) * 64 * CH_LD * sizeof(double), st, M, cp);
+    else hipLaunchKernelGGL(k_marginal_invchol, dim3(std::min(M.nlist, 8 * h->sm_count)), dim3(NT), lds, st, M, cp);
   }
   for (int g = g_lo; g < g_hi; ++g) {
     const LevelInfo &L = h->levels[g];
