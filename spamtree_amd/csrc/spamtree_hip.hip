@@ -662,7 +662,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       }
       L.fast = ok;
       if (!ok) { h->grps.resize(L.grp_first); L.grp_count = 0; }
-      if (!ok && !h->force_generic && L.maxM <= 80 && L.maxP <= BM_MAXP && L.maxP > 0) {
+      if (!ok && !h->force_generic && L.maxM <= 80 && L.maxP <= BM_MAXP) {   // (a root level, P = 0, included: its 75 x 75 factorisation is the blocked one of the epilogue)
         int ldS = L.maxP + 24;
         while ((ldS & 1) || ((ldS >> 1) & 1) == 0) ++ldS;
         L.bm_ldS = ldS;
