@@ -1609,12 +1609,126 @@ __global__ __launch_bounds__(NT, NCH <= 4 ? 4 : 3) void k_sample_leaf_seg(Sample
 template __global__ void k_sample_leaf_seg<4>(SampleFastArgs);
 template __global__ void k_sample_leaf_seg<6>(SampleFastArgs);
 
+// ---------------------------------------------------------------------------------------------------------------
+// Phase B, non-reference blocks of WIDE-block trees (the default multivariate tree: 36-row leaves behind seven 75-row
+// ancestors, config #4), which are not column groups and took the generic kernel's three passes over the panel (2.2 ms at #4).
+// The segment-aligned scheme of k_sample_leaf_seg with THREE 32-lane halves per ancestor (ancestors of at most 96 rows, at
+// most 8 of them: 24 halves = 12 register chunks): a wave owns whole rows, one coalesced pass over the panel, two rows at a
+// time.  One block per workgroup (a block's record is its own; non-reference blocks have no children).
+// spamtree_model.cpp:1091-1155, 1190-1203.
+__global__ __launch_bounds__(NT, 2) void k_sample_leaf_wide(SampleArgs A) {
+  constexpr int NCH = 12, NHA = 3;   // chunks; halves per ancestor
+  extern __shared__ double lds[];
+  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
+  __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
+  __shared__ int s_fail;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double *red = lds;                         // 4 x (64 NCH): per-wave column sums
+  double *tsq = red + 4 * 64 * NCH, *yx = tsq + 64, *zc = yx + 64;
+  const int hi = lane >> 5, li = lane & 31;
+  for (int bi = blockIdx.x; bi < A.nlist; bi += gridDim.x) {
+    const int b = A.list[bi];
+    const Blk B = A.blks[b];
+    const int M = B.m, P = B.P, J = B.nanc, ld = B.ld;   // M <= 64, J <= 8, ancestors <= 96 rows (host)
+    __syncthreads();
+    if (tid < J) {
+      const int a = A.anc_idx[B.anc_ptr + tid];
+      s_am[tid] = A.blks[a].m;
+      s_arow[tid] = A.blks[a].row0;
+    }
+    if (tid == 0) s_fail = 0;
+    if (tid >= 64 && tid < 64 + M) {
+      const int j = tid - 64;
+      const long long r = B.row0 + j;
+      tsq[j] = A.tausq_inv[A.mv[r]]; yx[j] = A.y[r] - A.xb[r]; zc[j] = A.z[r];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0;
+      long long ao = 0;
+      for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+      s_ao[J] = o; s_aoff[J] = ao;
+    }
+    __syncthreads();
+    // this lane's columns: chunk c, half hx = 2 c + hi -> ancestor t = hx / 3, its rows 32 (hx % 3) + li
+    int kc[NCH];
+    double wk[NCH], acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int hx = 2 * c + hi, t = hx / NHA, i = 32 * (hx - NHA * t) + li;
+      const bool ok = t < J && i < s_am[min(t, MAXJ - 1)];
+      kc[c] = ok ? s_ao[t] + i : -1;
+      wk[c] = ok ? A.w[s_arow[t] + i] : 0.0;
+      acc[c] = 0.0;
+    }
+    const double *pg = A.panels + B.panel_off;
+#pragma unroll 1
+    for (int j0 = 2 * wid; j0 < M; j0 += 2 * (NT / 64)) {
+      double v[2][NCH], rjv[2];
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int j = j0 + rr;
+        const double *src = pg + (size_t)min(j, M - 1) * ld;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v[rr][c] = (j < M && kc[c] >= 0) ? src[kc[c]] : 0.0;
+        rjv[rr] = j < M ? src[P] : 0.0;
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int j = j0 + rr;
+        if (j < M) {   // wave-uniform
+          double hs[2 * NCH];       // the sums of the 24 halves (wave-uniform)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            if (2 * c < NHA * J) {   // wave-uniform
+              double x = v[rr][c] * wk[c];
+              x = dpp_ror_add(x, 8); x = dpp_ror_add(x, 4); x = dpp_ror_add(x, 2); x = dpp_ror_add(x, 1);
+              hs[2 * c] = readlane_f64(x, 0) + readlane_f64(x, 16);
+              hs[2 * c + 1] = readlane_f64(x, 32) + readlane_f64(x, 48);
+            } else { hs[2 * c] = 0.0; hs[2 * c + 1] = 0.0; }
+          }
+          double sg[2 * NCH / NHA];   // per ancestor: its three halves in order
+          double tvj = 0.0;
+#pragma unroll
+          for (int t = 0; t < 2 * NCH / NHA; ++t) { sg[t] = (hs[NHA * t] + hs[NHA * t + 1]) + hs[NHA * t + 2]; tvj += sg[t]; }
+          const double rj = rjv[rr];
+          const double sig = rj * rj + tsq[j];
+          if (!(sig > 0.0) && lane == 0) s_fail = 1;
+          const double mu = -rj * tvj + tsq[j] * yx[j];
+          const double cc = 1.0 / sqrt(sig);
+          const double wj = cc * cc * mu + cc * zc[j];
+          if (lane == 0) A.w[B.row0 + j] = wj;
+          const double evj = rj * wj + tvj;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const double own = hi ? sg[(2 * c + 1) / NHA] : sg[(2 * c) / NHA];
+            acc[c] -= v[rr][c] * (evj - own);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) red[(wid * NCH + c) * 64 + lane] = acc[c];
+    __syncthreads();
+    double *rec = A.acc + B.acc_off;
+    for (int e = tid; e < 64 * NCH; e += NT) {
+      const int c = e >> 6, l = e & 63, hx = 2 * c + (l >> 5), t = hx / NHA, i = 32 * (hx - NHA * t) + (l & 31);
+      if (t < J && i < s_am[t]) {
+        const int ma = s_am[t];
+        rec[s_aoff[t] + (long long)ma * ma + i] = ((red[e] + red[64 * NCH + e]) + red[2 * 64 * NCH + e]) + red[3 * 64 * NCH + e];
+      }
+    }
+    if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + 11);
+  }
+}
+
 template __global__ void k_sample<false, false>(SampleArgs);
 template __global__ void k_sample<true, false>(SampleArgs);
 template __global__ void k_sample<true, true>(SampleArgs);
 #else   // host side: prototypes only (the kernels are compiled in their own translation unit)
 template <bool BIG, bool NOREF = false> __global__ void k_sample(SampleArgs A);
 __global__ void k_gram_big(GramBigArgs A);
+__global__ void k_sample_leaf_wide(SampleArgs A);
 __global__ void k_sample_mfma(SampleFastArgs A);
 __global__ void k_gram(SampleFastArgs A);
 __global__ void k_gram_direct(SampleFastArgs A);

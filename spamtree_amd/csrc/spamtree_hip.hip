@@ -151,6 +151,7 @@ struct st_handle_s {
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   int sample_wave = 1;                        // reference blocks of <= 27 rows: one block per wave (SPAMTREE_SAMPLE_WAVE=0: k_sample_lean)
+  int leaf_wide = 1;                          // k_sample_leaf_wide for the non-reference levels of wide-block trees (SPAMTREE_LEAF_WIDE=0: the generic kernel)
   int leaf_seg = 1;                           // k_sample_leaf_seg (segment-aligned lanes) where eligible
   int gram_direct_level = -1;                 // >= 0: that (last reference) level forms its children's Gram parts itself: k_gram_direct
   int split_gram = 1;                         // sweeps that rebuild the Gram parts: k_gram + lean kernels (SPAMTREE_SPLIT_GRAM=0: k_sample_mfma)
@@ -552,7 +553,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   auto geometry = [&](LevelInfo &L, const std::vector<int> &list, bool is_pred) {
     for (int b : list) {
       const Blk &B = h->blks[b];
-      L.maxP = std::max(L.maxP, B.P); L.maxM = std::max(L.maxM, B.m); L.maxLd = std::max(L.maxLd, B.ld);
+      L.maxP = std::max(L.maxP, B.P); L.maxM = std::max(L.maxM, B.m); L.maxLd = std::max(L.maxLd, B.ld); L.maxJ = std::max(L.maxJ, B.nanc);
       for (int t = 0; t < B.nanc; ++t) L.maxMa = std::max(L.maxMa, h->blks[h->anc_idx[B.anc_ptr + t]].m);
       // algorithmic bytes / flops, SURVEY.md section 8d
       const double m = B.m, P = B.P, tri = P * (P + 1) / 2, rim = B.isref ? m * (m + 1) / 2 : m;
@@ -1196,6 +1197,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     h->factor_gen = (e && e[0] == '1') ? 1 : 3;
     { const char *e2 = getenv("SPAMTREE_SAMPLE_LEAN"); h->sample_lean = (e2 && e2[0] == '0') ? 0 : 1; }
     { const char *e2 = getenv("SPAMTREE_LEAF_SEG"); h->leaf_seg = (e2 && e2[0] == '0') ? 0 : 1; }
+    { const char *e2 = getenv("SPAMTREE_LEAF_WIDE"); h->leaf_wide = (e2 && e2[0] == '0') ? 0 : 1; }
     { const char *e2 = getenv("SPAMTREE_SPLIT_GRAM"); h->split_gram = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }
     { const char *e2 = getenv("SPAMTREE_SAMPLE_WAVE"); h->sample_wave = (e2 && e2[0] == '0') ? 0 : ((e2 && e2[0] == '2') ? 2 : 1); }   // 2: every eligible level (tests)
   }
@@ -1899,6 +1901,8 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
         if (L.big_sample) {
           A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
           if (L.isref) hipLaunchKernelGGL((k_sample<true, false>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
+          else if (h->leaf_wide && !A.do_gram && L.maxM <= 64 && L.maxMa <= 96 && L.maxJ <= 8)   // one coalesced pass, segment-aligned lanes
+            hipLaunchKernelGGL(k_sample_leaf_wide, dim3(std::min(L.own_n, 16 * h->sm_count)), dim3(NT), ((size_t)4 * 64 * 12 + 3 * 64) * 8, h->stream, A);
           else hipLaunchKernelGGL((k_sample<true, true>), dim3(std::min(L.own_n, h->scratch_wgs)), dim3(NT), L.lds_sample, h->stream, A);
         } else {
           hipLaunchKernelGGL((k_sample<false>), dim3(L.own_n), dim3(NT), L.lds_sample, h->stream, A);
