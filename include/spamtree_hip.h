@@ -174,6 +174,7 @@ int st_profile_levels(st_handle h, int32_t *n_levels, double *ms_by_level, doubl
 #define ST_KERNEL_BIGMFMA 4
 #define ST_KERNEL_WIDE 5
 #define ST_KERNEL_LCHAIN 6
+#define ST_KERNEL_LCHAIN_REF 7   /* reference level: k_factor_lchain for the chain pass + k_factor_ref_finish per block */
 int st_level_info(st_handle h, int32_t *n_levels, int32_t *kernel, int32_t *max_m, int32_t *max_P, int32_t *n_blocks, int32_t cap);
 int st_synchronize(st_handle h);
 void *st_stream(st_handle h);                              /* the hipStream_t every kernel is launched on */

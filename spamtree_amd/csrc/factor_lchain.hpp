@@ -57,6 +57,8 @@ struct LcArgs {
   double *rowtmp;   // per device row: e_j^2 | log r_j (2 x n_rows), summed per block by k_lchain_scalars in row order
   long long n_rows;
   int *errflag;
+  int errcode;      // what a non-positive conditional variance reports: 3 on non-reference levels (spamtree_model.cpp:958); 2 when the
+                    // kernel runs as the first half of a REFERENCE level (k_factor_ref_finish completes it; :919)
 };
 
 #ifdef ST_DEFS_FACTOR_WIDE
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
     }
   }
   __syncthreads();
-  if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + 3);
+  if (tid == 0 && s_fail) atomicMin(A.errflag, B.level * 16 + A.errcode);
   STAMP(11);
   STAMP_FLUSH_LEVEL(B.level);
 #ifdef FM_STAMPS

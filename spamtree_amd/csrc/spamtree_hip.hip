@@ -75,6 +75,8 @@ struct LevelInfo {
   int bm_ldS = 0;
   size_t lds_bigmfma = 0;
   int lchain = 0;                  // non-reference level on k_factor_lchain<lchain> (0: not used)
+  bool lchain_ref = false;         // ... a REFERENCE level: k_factor_lchain, then k_factor_ref_finish
+  size_t lds_ref_finish = 0;
   int lc_first = 0, lc_count = 0;  // its slabs (this rank's run) in d_lcslabs
   int quad_first = 0, quad_count = 0, qown_lo = 0, qown_n = 0, q_ldS = 0, q_nkx = 0;   // k_factor_quad (q_nkx = 0: not eligible)
   size_t lds_quad = 0;
@@ -151,6 +153,7 @@ struct st_handle_s {
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   int sample_wave = 1;                        // reference blocks of <= 27 rows: one block per wave (SPAMTREE_SAMPLE_WAVE=0: k_sample_lean)
+  int lchain_ref_on = 1, lchain_ref_min = 256;   // reference levels of wide-block trees with at least that many blocks: k_factor_lchain + k_factor_ref_finish
   int leaf_wide = 1;                          // k_sample_leaf_wide for the non-reference levels of wide-block trees (SPAMTREE_LEAF_WIDE=0: the generic kernel)
   int leaf_seg = 1;                           // k_sample_leaf_seg (segment-aligned lanes) where eligible
   int gram_direct_level = -1;                 // >= 0: that (last reference) level forms its children's Gram parts itself: k_gram_direct
@@ -547,6 +550,8 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     h->quad_nu = 4;   // units per workgroup of k_factor_quad (2 per workgroup with two workgroups per CU measured slower)
     { const char *e = getenv("SPAMTREE_WIDE"); h->wide_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
     { const char *e = getenv("SPAMTREE_LCHAIN"); h->lchain_on = (e && e[0] == '0') ? 0 : 1; }
+    { const char *e = getenv("SPAMTREE_LCHAIN_REF"); h->lchain_ref_on = (e && e[0] == '0') ? 0 : 1; }
+    { const char *e = getenv("SPAMTREE_LCHAIN_REF_MIN"); h->lchain_ref_min = e ? atoi(e) : 256; }
     { const char *e = getenv("SPAMTREE_GRAM_BIG"); h->gram_big = (e && e[0] == '0') ? 0 : 1; }
   }
   h->levels.resize(n_actual);
@@ -676,6 +681,13 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
           bool all_anc = true;
           for (int b : list) all_anc = all_anc && h->blks[b].nanc >= 1 && !h->blks[b].isref;
           if (all_anc) L.lchain = L.maxP <= 384 ? 96 : 136;
+        }
+        // REFERENCE levels of many blocks (round 3): k_factor_lchain for the chain pass (it runs it at more than twice
+        // k_factor_bigmfma's rate), then k_factor_ref_finish per block.  L.count, not the rank's share: a property of the level
+        if (L.bigmfma && h->lchain_on && h->lchain_ref_on && !h->limited && L.isref && L.maxM <= 80 && L.maxP <= 544 && L.count >= h->lchain_ref_min) {
+          bool all_anc = true;
+          for (int b : list) all_anc = all_anc && h->blks[b].nanc >= 1 && h->blks[b].isref;
+          if (all_anc) { L.lchain = L.maxP <= 384 ? 96 : 136; L.lchain_ref = true; }
         }
       }
     }
@@ -1178,8 +1190,13 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     for (auto &L : h->levels) {
       if (!L.lchain) continue;
       const size_t need = lc_dyn_doubles(L.lchain) * 8 + (L.lchain == 96 ? st96 : st136);
-      if (need > 160 * 1024 || !(L.lchain == 96 ? ok96 : ok136)) L.lchain = 0;
+      if (need > 160 * 1024 || !(L.lchain == 96 ? ok96 : ok136)) { L.lchain = 0; L.lchain_ref = false; }
+      if (L.lchain_ref) {
+        L.lds_ref_finish = ((size_t)3 * (L.maxP + L.maxM) + 10 * (size_t)L.maxM + 2 * (size_t)L.maxM * L.maxM) * 8 + (size_t)((L.maxP + L.maxM + 1) & ~1) * 4 + 64;
+        if (L.lds_ref_finish > h->lds_limit) { L.lchain = 0; L.lchain_ref = false; }
+      }
     }
+    (void)hipFuncSetAttribute((const void *)k_factor_ref_finish, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
     (void)hipFuncSetAttribute((const void *)k_factor_lchain<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lc_dyn_doubles(96) * 8));
     (void)hipFuncSetAttribute((const void *)k_factor_lchain<136>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lc_dyn_doubles(136) * 8));
   }
@@ -1480,8 +1497,13 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         C.blks = h->d_blks.p; C.anc_idx = h->d_anc.p; C.slabs = h->d_lcslabs.p + L.lc_first; C.nslab = L.lc_count;
         C.cx = h->d_cx.p; C.cy = h->d_cy.p; C.mv = h->d_mv.p; C.w_in = h->d_w.p; C.panels = h->d_panels[phys].p;
         C.rowtmp = h->d_lcrow.p; C.n_rows = h->n_all; C.errflag = errflag;
+        C.errcode = L.lchain_ref ? 2 : 3;
         if (L.lchain == 96) hipLaunchKernelGGL((k_factor_lchain<96>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(96) * 8, st, C, cp);
         else hipLaunchKernelGGL((k_factor_lchain<136>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(136) * 8, st, C, cp);
+        if (L.lchain_ref) {   // the panels hold [ -r_j T_j | r_j ] per column: finish the blocks (Schur complement, factorisation, -Ri T in place)
+          A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
+          hipLaunchKernelGGL(k_factor_ref_finish, dim3(std::min(A.nlist, std::min(h->scratch_wgs, 2 * h->sm_count))), dim3(BM_NT), L.lds_ref_finish, st, A, cp);
+        } else
         hipLaunchKernelGGL(k_lchain_scalars, dim3((A.nlist + 255) / 256), dim3(256), 0, st, h->d_blks.p, A.list, A.nlist, h->d_lcrow.p, h->n_all,
                            h->d_logdet[phys].p, h->d_loglik[phys].p);
       } else if (L.bigmfma && h->factor_gen == 3 && L.wide_count > 0) {
@@ -2315,7 +2337,7 @@ extern "C" int st_level_info(st_handle h, int32_t *n_levels, int32_t *kernel, in
     int k = L.big_factor ? ST_KERNEL_GENERIC_SCRATCH : ST_KERNEL_GENERIC_LDS;
     if (L.fast && h->factor_gen == 3 && L.q_nkx > 0) k = ST_KERNEL_QUAD;
     else if (L.fast) k = ST_KERNEL_MFMA;
-    else if (L.bigmfma && h->factor_gen == 3) k = L.lchain ? ST_KERNEL_LCHAIN : (L.wide_count > 0 ? ST_KERNEL_WIDE : ST_KERNEL_BIGMFMA);
+    else if (L.bigmfma && h->factor_gen == 3) k = L.lchain ? (L.lchain_ref ? ST_KERNEL_LCHAIN_REF : ST_KERNEL_LCHAIN) : (L.wide_count > 0 ? ST_KERNEL_WIDE : ST_KERNEL_BIGMFMA);
     if (kernel) kernel[g] = k;
     if (max_m) max_m[g] = L.maxM;
     if (max_P) max_P[g] = L.maxP;

@@ -276,7 +276,7 @@ class SpamTreeMV:
         self._check(self.lib.st_profile_levels(self.h, C.byref(nl), _dp(ms), _dp(by), 128))
         return ms[nl.value: 2 * nl.value].copy(), by[nl.value: 2 * nl.value].copy()
 
-    KERNEL_NAMES = ["generic_lds", "generic_scratch", "k_factor_mfma", "k_factor_quad", "k_factor_bigmfma", "k_factor_wide", "k_factor_lchain"]
+    KERNEL_NAMES = ["generic_lds", "generic_scratch", "k_factor_mfma", "k_factor_quad", "k_factor_bigmfma", "k_factor_wide", "k_factor_lchain", "k_factor_lchain+ref_finish"]
 
     def level_info(self):
         """Per observed level: dict(kernel=name of the phase-A kernel, max_m, max_P, n_blocks)."""

@@ -82,3 +82,20 @@ def test_config5_chains_201_to_256_on_k_factor_mfma():
         assert info[9]["max_P"] > 200 and info[8]["max_P"] > 200                      # beyond k_factor_quad's register budget
 
     compare_all(pb, expect)
+
+
+@pytest.mark.parametrize("nx", [370, 400])
+def test_config4_reference_levels_on_lchain_and_ref_finish(nx, monkeypatch):
+    """Reference levels of a wide-block tree as k_factor_lchain (chain pass, columns treated as conditionally independent)
+    + k_factor_ref_finish (Schur complement, blocked factorisation, -Ri T in place): by default only levels of >= 256 blocks
+    take this route (config #4's levels 5-6); SPAMTREE_LCHAIN_REF_MIN=1 puts every reference level behind a chain on it."""
+    monkeypatch.setenv("SPAMTREE_LCHAIN_REF_MIN", "1")
+    coords, mv = strip_coords(nx, 10, 3)
+    pb = make_problem(coords=coords, mv_id=mv, q=3, seed=3, K=(2, 1), tree_depth=7)
+
+    def expect(info):
+        assert len(info) == 8 and all(L["kernel"] == "k_factor_lchain+ref_finish" for L in info[1:7])
+        assert info[7]["kernel"] == "k_factor_lchain"
+        assert info[6]["max_m"] > 64 and info[6]["max_P"] == 450
+
+    compare_all(pb, expect)
