@@ -372,194 +372,9 @@ __global__ __launch_bounds__(BM_NT, 2) void k_factor_bigmfma(FactorArgs A, CovPa
   }
   STAMP_FLUSH_LEVEL(st_level);
 }
-// ---------------------------------------------------------------------------------------------------------------
-// Second half of phase A for REFERENCE levels of wide-block trees (round 3).  k_factor_bigmfma walks a block's chain as one
-// latency chain per workgroup (28 sub-panels of ~22 us at config #4: 13-15 % of the FP64 pipe); k_factor_lchain, built for the
-// non-reference levels, runs the same chain pass at 36 %.  A reference level therefore takes k_factor_lchain FIRST -- it treats
-// the columns as conditionally independent and leaves, per column j, the panel row [ -r_j T_j | r_j ] with T = H_u and
-// r_j = (K_jj - T_j K_pa,j)^(-1/2) -- and this kernel finishes the block (spamtree_model.cpp:880-922):
-//   T = -(row) / r_j;   R = K_uu - T K_pa,u  (= K_uu - V'V: T K = K' Linv' Linv K);   Ri = chol(R)^-1 (blocked, LDS);
-//   panel <- [ -Ri T | Ri ] IN PLACE (a wave owns 16-column blocks of the chain: it reads the block's 75 x 16 entries of T before
-//   it writes them);   e = Ri w_u + N w_pa;   logdet, loglik.
-// K_pa,u is evaluated again (as cheap as the first time: 6 % of k_factor_bigmfma) into the workgroup's scratch slice and feeds the
-// Schur product's B operands from L2 -- one pass of 113 K-steps per tile pair, not one per sub-panel.
-__global__ __launch_bounds__(BM_NT, 2) void k_factor_ref_finish(FactorArgs A, CovPar cp) {
-  extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ];
-  __shared__ int s_fail;
-  __shared__ double s_red[BM_NT / 64];
-  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int maxP = A.maxP, maxM = A.maxM;
-  double *sx = lds;
-  double *sy = sx + (maxP + maxM);
-  double *wv = sy + (maxP + maxM);
-  double *hv = wv + (maxP + maxM);     // maxM: N w_pa
-  double *rinv = hv + maxM;            // maxM: 1 / r_j
-  double *hp = rinv + maxM;            // 8 x maxM: per-wave partial sums of N w_pa
-  double *Rl = hp + (size_t)8 * maxM;  // maxM^2
-  double *Ril = Rl + (size_t)maxM * maxM;
-  int *smv = (int *)(Ril + (size_t)maxM * maxM);
-  double *KV = A.scratch + (size_t)blockIdx.x * A.scratch_stride;   // K_pa,u, row k at k * m
-  for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
-    const int b = A.list[li];
-    const Blk B = A.blks[b];
-    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
-    const int JT = (m + 15) >> 4;
-    double *pu = A.panels + B.panel_off;
-    __syncthreads();
-    if (tid < J) {
-      const int a = A.anc_idx[B.anc_ptr + tid];
-      s_am[tid] = A.blks[a].m; s_arow[tid] = A.blks[a].row0;
-    }
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-      s_ao[J] = o;
-    }
-    __syncthreads();
-    for (int t = 0; t < J; ++t) {
-      const long long r0 = s_arow[t];
-      const int oa = s_ao[t];
-      for (int i = tid; i < s_am[t]; i += BM_NT) { sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i]; }
-    }
-    for (int i = tid; i < m; i += BM_NT) {
-      sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
-      const double r = pu[(size_t)i * ld + P];
-      if (!(r > 0.0) || !(r < 1e300)) s_fail = 1;    // k_factor_lchain met a non-positive conditional variance (it flagged it too)
-      rinv[i] = 1.0 / r;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < P * m; idx += BM_NT) {
-      const int k = idx / m, j = idx - k * m;
-      KV[idx] = cov_entry(cp, sx[k], sy[k], smv[k], sx[P + j], sy[P + j], smv[P + j]);
-    }
-    for (int idx = tid; idx < m * m; idx += BM_NT) Rl[idx] = 0.0;
-    __syncthreads();
-    // ---- R = K_uu - T K_pa,u (lower triangle): A[i][k] = T[i][k] = -row_i[k] / r_i from the panel, B[k][j] = K[k][j] from the slice
-    {
-      const int ns = (P + 3) >> 2;
-      for (int e = wid; e < JT * (JT + 1) / 2; e += BM_NT / 64) {
-        int it = 0;
-        while ((it + 1) * (it + 2) / 2 <= e) ++it;
-        const int jt = e - it * (it + 1) / 2;
-        const int ci = it * 16 + l15, cj = jt * 16 + l15;
-        const double *ap = pu + (size_t)min(ci, m - 1) * ld + l4, *bp = KV + (size_t)l4 * m + min(cj, m - 1);
-        const double sa = ci < m ? -rinv[min(ci, m - 1)] : 0.0;
-        d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-        int st = 0;
-        for (; st + 4 <= ns; st += 4) {
-          double a4[4], b4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool kok = 4 * (st + q) + l4 < P;
-            a4[q] = kok ? ap[4 * (st + q)] * sa : 0.0;
-            b4[q] = (kok && cj < m) ? bp[(size_t)4 * (st + q) * m] : 0.0;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
-        }
-        for (; st < ns; ++st) {
-          const bool kok = 4 * st + l4 < P;
-          const double a1 = kok ? ap[4 * st] * sa : 0.0, b1 = (kok && cj < m) ? bp[(size_t)4 * st * m] : 0.0;
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = it * 16 + l4 + 4 * r, j = jt * 16 + l15;
-          if (i < m && j <= i) Rl[i * m + j] = cov_entry(cp, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]) - c[r];
-        }
-      }
-    }
-    __syncthreads();
-    block_chol_invert_mfma(Rl, Ril, m, &s_fail);
-    // ---- panel <- -Ri T in place: wave w owns chain column blocks kt = w, w + 8, ...; it holds the block's T entries (all rows of
-    // the unit: <= 80 = 20 K-steps) in registers before any of them is overwritten.  N w_pa rides along.
-    {
-      const int nkt = (P + 15) >> 4, njs = (m + 3) >> 2;
-      double hvp[5][4];
-#pragma unroll
-      for (int it = 0; it < 5; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hvp[it][r] = 0.0;
-      for (int kt = wid; kt < nkt; kt += BM_NT / 64) {
-        const int kb = kt * 16 + l15;
-        double tb[20];   // B operands: T[j = 4 s + l4][kb]
-#pragma unroll
-        for (int s2 = 0; s2 < 20; ++s2) {
-          const int j = 4 * s2 + l4;
-          tb[s2] = (s2 < njs && j < m && kb < P) ? -pu[(size_t)j * ld + kb] * rinv[min(j, m - 1)] : 0.0;
-        }
-        const double wk = kb < P ? wv[kb] : 0.0;
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-          if (it < JT) {
-            const int ia = it * 16 + l15;
-            d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s2 = 0; s2 < 20; ++s2) {
-              if (s2 < njs && 4 * s2 < it * 16 + 16) {   // Ri is lower triangular: row tile `it` needs columns < 16 (it + 1)
-                const int j = 4 * s2 + l4;
-                const double a1 = (ia < m && j <= ia) ? -Ril[ia * m + j] : 0.0;
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, tb[s2], c, 0, 0, 0);
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = it * 16 + l4 + 4 * r;
-              if (i < m && kb < P) pu[(size_t)i * ld + kb] = c[r];
-              hvp[it][r] = fma(c[r], wk, hvp[it][r]);
-            }
-          }
-        }
-      }
-      // (N w_pa)[i] = sum over the chain columns: this wave's share, summed over its 16 column lanes
-#pragma unroll
-      for (int it = 0; it < 5; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double x = hvp[it][r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
-          const int i = it * 16 + l4 + 4 * r;
-          if (l15 == 0 && i < m) hp[wid * maxM + i] = x;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < m; i += BM_NT) {
-      double a = 0.0;
-      for (int w8 = 0; w8 < BM_NT / 64; ++w8) a += hp[w8 * maxM + i];
-      hv[i] = a;   // = N w_pa
-    }
-    for (int idx = tid; idx < m * m; idx += BM_NT) {
-      const int i = idx / m, j = idx - i * m;
-      pu[(size_t)i * ld + P + j] = (j <= i) ? Ril[idx] : 0.0;
-    }
-    __syncthreads();
-    double wcore_part = 0.0, logdet_part = 0.0;
-    for (int i = tid; i < m; i += BM_NT) {   // e = Ri w_u + N w_pa
-      double acc = hv[i];
-      for (int j = 0; j <= i; ++j) acc += Ril[i * m + j] * wv[P + j];
-      wcore_part += acc * acc;
-      logdet_part += log(Ril[i * m + i]);
-    }
-    const double wcore = block_sum(wcore_part, s_red);
-    const double logdet = block_sum(logdet_part, s_red);
-    __syncthreads();
-    if (tid == 0) {
-      A.logdet_c[b] = logdet;
-      A.loglik_c[b] = (double)m * HL2PI - 0.5 * wcore;
-      if (s_fail) atomicMin(A.errflag, B.level * 16 + 2);
-    }
-  }
-}
 template __global__ void k_factor_bigmfma<3, 5, 34>(FactorArgs, CovPar);
 template __global__ void k_factor_bigmfma<4, 5, 34>(FactorArgs, CovPar);
 template __global__ void k_factor_bigmfma<5, 3, 24>(FactorArgs, CovPar);
 #else   // host side: prototypes only
 template <int BM_JT, int BM_KTW, int BM_KTP> __global__ void k_factor_bigmfma(FactorArgs A, CovPar cp);
-__global__ void k_factor_ref_finish(FactorArgs A, CovPar cp);
 #endif

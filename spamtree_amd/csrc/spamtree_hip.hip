@@ -1192,7 +1192,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
       const size_t need = lc_dyn_doubles(L.lchain) * 8 + (L.lchain == 96 ? st96 : st136);
       if (need > 160 * 1024 || !(L.lchain == 96 ? ok96 : ok136)) { L.lchain = 0; L.lchain_ref = false; }
       if (L.lchain_ref) {
-        L.lds_ref_finish = ((size_t)3 * (L.maxP + L.maxM) + 10 * (size_t)L.maxM + 2 * (size_t)L.maxM * L.maxM) * 8 + (size_t)((L.maxP + L.maxM + 1) & ~1) * 4 + 64;
+        L.lds_ref_finish = rf_lds_bytes(L.maxP, L.maxM);
         if (L.lds_ref_finish > h->lds_limit) { L.lchain = 0; L.lchain_ref = false; }
       }
     }
@@ -1501,8 +1501,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         if (L.lchain == 96) hipLaunchKernelGGL((k_factor_lchain<96>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(96) * 8, st, C, cp);
         else hipLaunchKernelGGL((k_factor_lchain<136>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(136) * 8, st, C, cp);
         if (L.lchain_ref) {   // the panels hold [ -r_j T_j | r_j ] per column: finish the blocks (Schur complement, factorisation, -Ri T in place)
-          A.scratch = h->d_scratch.p; A.scratch_stride = h->scratch_stride;
-          hipLaunchKernelGGL(k_factor_ref_finish, dim3(std::min(A.nlist, std::min(h->scratch_wgs, 2 * h->sm_count))), dim3(BM_NT), L.lds_ref_finish, st, A, cp);
+          hipLaunchKernelGGL(k_factor_ref_finish, dim3(std::min(A.nlist, 2 * h->sm_count)), dim3(BM_NT), L.lds_ref_finish, st, A, cp);
         } else
         hipLaunchKernelGGL(k_lchain_scalars, dim3((A.nlist + 255) / 256), dim3(256), 0, st, h->d_blks.p, A.list, A.nlist, h->d_lcrow.p, h->n_all,
                            h->d_logdet[phys].p, h->d_loglik[phys].p);
