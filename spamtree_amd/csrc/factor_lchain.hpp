@@ -42,7 +42,8 @@ struct LcSlab {
   long long row0;   // first device row (column) of the slab
   long long pan0;   // panel arena offset of that row's panel row (rows of the group follow each other with stride ld)
   int blk0;         // a block of the group: chain, level
-  int ncol, ld, pad;
+  int ncol, ld, ldv;
+  long long vs0;    // reference levels: where the slab's first column starts in the V scratch (row stride ldv = the group's columns)
 };
 
 struct LcArgs {
@@ -57,23 +58,23 @@ struct LcArgs {
   double *rowtmp;   // per device row: e_j^2 | log r_j (2 x n_rows), summed per block by k_lchain_scalars in row order
   long long n_rows;
   int *errflag;
+  double *vscr;     // reference levels: V = Linv_pa K_pa,u goes here for k_factor_ref_finish's Schur complement (nullptr: not stored)
   int errcode;      // what a non-positive conditional variance reports: 3 on non-reference levels (spamtree_model.cpp:958); 2 when the
                     // kernel runs as the first half of a REFERENCE level (k_factor_ref_finish completes it; :919)
 };
 
-// k_factor_ref_finish (second half of a REFERENCE level on this route): the Schur product R = K_uu - T K_pa,u walks the chain in
-// chunks of RF_KC rows staged in LDS -- T's chunk from the panel, K's chunk evaluated straight into LDS, never through memory --
-// in two buffers that overlay R / Ri (free until the product is complete)
-#define RF_KC 32
-#define RF_LDA 34    // row stride of a staged T chunk: 2 x odd (conflict-free A-operand reads)
-#define RF_LDB 80    // row stride of a staged K chunk: 80 = 16 mod 32 (the four K rows of a B operand fall into alternate bank halves)
-#define RF_BUF (80 * RF_LDA + RF_KC * RF_LDB)
+// k_factor_ref_finish (second half of a REFERENCE level on this route): the Schur complement R = K_uu - V'V walks the chain in
+// chunks of RF_KC rows of V (left in a scratch by k_factor_lchain) staged in LDS, in two buffers that overlay R / Ri (free until
+// the product is complete)
+#define RF_KC 64
+#define RF_LDB 80    // row stride of a staged chunk: 80 = 16 mod 32 (the four K rows of an operand fall into alternate bank halves)
+#define RF_BUF (RF_KC * RF_LDB)
 __host__ __device__ constexpr size_t rf_work_doubles(int maxM) {
   const size_t a = (size_t)2 * maxM * maxM, b = (size_t)2 * RF_BUF;
   return a > b ? a : b;
 }
-__host__ __device__ constexpr size_t rf_lds_bytes(int maxP, int maxM) {
-  return ((size_t)3 * (maxP + maxM) + 10 * (size_t)maxM + rf_work_doubles(maxM)) * 8 + (size_t)((maxP + maxM + 1) & ~1) * 4 + 64;
+__host__ __device__ constexpr size_t rf_lds_bytes(int maxM) {   // w, x, y, T w_pa, 1 / r of the block | work | outcome ids
+  return (5 * (size_t)maxM + rf_work_doubles(maxM)) * 8 + (size_t)((maxM + 1) & ~1) * 4 + 64;
 }
 
 #ifdef ST_DEFS_FACTOR_WIDE
@@ -395,6 +396,12 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
       }
     }
     lds_barrier();   // phase 2 reuses the buffers
+    if (A.vscr && cok) {   // reference level: V (the B-operand layout: kx[st] = V[4 st + l4][column]) for k_factor_ref_finish
+      double *vp = A.vscr + S.vs0 + jc + (size_t)l4 * S.ldv;
+#pragma unroll
+      for (int st = 0; st < NKX; ++st)
+        if (4 * st + l4 < P) vp[(size_t)4 * st * S.ldv] = kx[st];
+    }
     STAMP(6);
 
     // ---- r_j = 1 / sqrt(K_jj - sum_k V_kj^2)  (spamtree_model.cpp:944-951)
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
     const double hvc = (l15 >> 2) == 0 ? t0 : ((l15 >> 2) == 1 ? t1 : ((l15 >> 2) == 2 ? t2 : t3));
     if (cok && l4 == 0) {
       const double e = rj * (wj - hvc);
-      A.rowtmp[jrow] = e * e;
+      A.rowtmp[jrow] = A.vscr ? hvc : e * e;   // (reference level: T w_pa itself, for k_factor_ref_finish's e = Ri (w_u - T w_pa))
       A.rowtmp[A.n_rows + jrow] = log(rj);
       A.panels[S.pan0 + (size_t)jc * S.ld + P] = rj;
     }
@@ -532,43 +539,29 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
 // latency chain per workgroup (28 sub-panels of ~22 us at config #4: 13-15 % of the FP64 pipe); k_factor_lchain, built for the
 // non-reference levels, runs the same chain pass at 36 %.  A reference level therefore takes k_factor_lchain FIRST -- it treats
 // the columns as conditionally independent and leaves, per column j, the panel row [ -r_j T_j | r_j ] with T = H_u and
-// r_j = (K_jj - T_j K_pa,j)^(-1/2) -- and this kernel finishes the block (spamtree_model.cpp:880-922):
-//   T = -(row) / r_j;   R = K_uu - T K_pa,u  (= K_uu - V'V: T K = K' Linv' Linv K);   Ri = chol(R)^-1 (blocked, LDS);
-//   panel <- [ -Ri T | Ri ] IN PLACE (a wave owns 16-column blocks of the chain: it reads the block's 75 x 16 entries of T before
-//   it writes them; the next block's entries are requested before the current block's MFMAs);   e = Ri w_u + N w_pa;   logdet, loglik.
-// The Schur product is a GEMM-style K loop: per chunk of RF_KC chain rows, T's chunk (scaled panel entries, requested one chunk
-// ahead) and K_pa,u's chunk (evaluated from the coordinates) go to LDS, one barrier, and the 15 lower tile pairs take their eight
-// K-steps from there -- the first version fed the matrix cores with 8-byte loads from the panel and from a scratch slice: 48 % of the kernel.
-template <bool MV>
-__device__ __forceinline__ void rf_cov_chunk(double *Kc, const double *tab, int qn, double s2, double nphi, const double *sx, const double *sy, const int *smv,
-                                             int P, int m, int k0, int tid) {
-#pragma unroll
-  for (int e = 0; e < (RF_KC * RF_LDB) / BM_NT; ++e) {
-    const int idx = tid + BM_NT * e, kk = idx / RF_LDB, j = idx - kk * RF_LDB, k = k0 + kk;
-    const int kc = min(k, P - 1), jc = P + min(j, m - 1);
-    const double v = lc_cov<MV>(tab, qn, s2, nphi, sx[kc], sy[kc], smv[kc], sx[jc], sy[jc], smv[jc]);
-    Kc[idx] = (j < m && k < P) ? v : 0.0;
-  }
-}
-
+// r_j = (K_jj - sum_k V_kj^2)^(-1/2), and V = Linv_pa K_pa,u in a scratch -- and this kernel finishes the block
+// (spamtree_model.cpp:880-922):
+//   R = K_uu - V'V   (a GEMM-style K loop: chunks of RF_KC rows of V through LDS, requested one chunk ahead, one barrier per chunk, the
+//                     15 lower tile pairs dealt over the eight waves; both operands of a K-step come from the same chunk);
+//   Ri = chol(R)^-1  (blocked, LDS);
+//   panel <- [ -Ri T | Ri ] with T = -(row) / r_j, IN PLACE (a wave owns 16-column blocks of the chain: it holds the block's 75 x 16
+//                     entries of T before it writes them; the next block's entries are requested before the current block's MFMAs);
+//   e = Ri w_u + N w_pa;   logdet, loglik.
 __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPar cp) {
   extern __shared__ double lds[];
-  __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
-  __shared__ long long s_arow[MAXJ];
   __shared__ int s_fail;
   __shared__ double s_red[BM_NT / 64];
   __shared__ double s_cpt[3 * QMAX * QMAX + QMAX];
-  static_assert((RF_KC * RF_LDB) % BM_NT == 0 && (80 * RF_KC) % BM_NT == 0, "chunk shapes");
+  static_assert(RF_BUF % BM_NT == 0, "chunk shape");
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int maxP = A.maxP, maxM = A.maxM;
-  double *sx = lds;
-  double *sy = sx + (maxP + maxM);
-  double *wv = sy + (maxP + maxM);
-  double *hv = wv + (maxP + maxM);     // maxM: N w_pa
-  double *rinv = hv + maxM;            // maxM: 1 / r_j
-  double *hp = rinv + maxM;            // 8 x maxM: per-wave partial sums of N w_pa
-  double *work = hp + (size_t)8 * maxM;   // the Schur product's staging buffers, then R | Ri
+  const int maxM = A.maxM;
+  double *wv = lds;                    // maxM each: the block's w, coordinates, T w_pa, 1 / r_j
+  double *sx = wv + maxM;
+  double *sy = sx + maxM;
+  double *hv = sy + maxM;
+  double *rinv = hv + maxM;
+  double *work = rinv + maxM;   // the Schur product's staging buffers, then R | Ri
   double *Rl = work;
   double *Ril = Rl + (size_t)maxM * maxM;
   int *smv = (int *)(work + rf_work_doubles(maxM));
@@ -583,37 +576,33 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
   for (int li = blockIdx.x; li < A.nlist; li += gridDim.x) {
     const int b = A.list[li];
     const Blk B = A.blks[b];
-    const int m = B.m, P = B.P, J = B.nanc, ld = B.ld;
+    const int m = B.m, P = B.P, ld = B.ld;
     const int JT = (m + 15) >> 4;
     double *pu = A.panels + B.panel_off;
+    const double *Vb = A.vscr + A.voff[li];
+    const int ldv = A.vld[li];
     st_level = B.level;
     __syncthreads();
-    if (tid < J) {
-      const int a = A.anc_idx[B.anc_ptr + tid];
-      s_am[tid] = A.blks[a].m; s_arow[tid] = A.blks[a].row0;
-    }
     if (tid == 0) s_fail = 0;
+    // V's first chunk is requested before anything else: entry (chain row k0 + idx / 80, column idx % 80), idx = tid + BM_NT e
+    double vp[RF_BUF / BM_NT];
+    auto loadV = [&](int k0) {
+#pragma unroll
+      for (int e = 0; e < RF_BUF / BM_NT; ++e) {
+        const int idx = tid + BM_NT * e, kk = idx / RF_LDB, j = idx - kk * RF_LDB, k = k0 + kk;
+        vp[e] = (j < m && k < P) ? Vb[(size_t)k * ldv + j] : 0.0;
+      }
+    };
+    loadV(0);
     __syncthreads();
-    if (tid == 0) {
-      int o = 0;
-      for (int t = 0; t < J; ++t) { s_ao[t] = o; o += s_am[t]; }
-      s_ao[J] = o;
-    }
-    __syncthreads();
-    for (int t = 0; t < J; ++t) {
-      const long long r0 = s_arow[t];
-      const int oa = s_ao[t];
-      for (int i = tid; i < s_am[t]; i += BM_NT) { sx[oa + i] = A.cx[r0 + i]; sy[oa + i] = A.cy[r0 + i]; smv[oa + i] = A.mv[r0 + i]; wv[oa + i] = A.w_in[r0 + i]; }
-    }
     for (int i = tid; i < m; i += BM_NT) {
-      sx[P + i] = A.cx[B.row0 + i]; sy[P + i] = A.cy[B.row0 + i]; smv[P + i] = A.mv[B.row0 + i]; wv[P + i] = A.w_in[B.row0 + i];
+      sx[i] = A.cx[B.row0 + i]; sy[i] = A.cy[B.row0 + i]; smv[i] = A.mv[B.row0 + i]; wv[i] = A.w_in[B.row0 + i]; hv[i] = A.hvrow[B.row0 + i];
       const double r = pu[(size_t)i * ld + P];
       if (!(r > 0.0) || !(r < 1e300)) s_fail = 1;    // k_factor_lchain met a non-positive conditional variance (it flagged it too)
       rinv[i] = 1.0 / r;
     }
-    __syncthreads();
     STAMP(0);
-    // ---- R = K_uu - T K_pa,u (lower tile pairs (it, jt <= it); a wave owns pairs wid and wid + 8)
+    // ---- R = K_uu - V'V (lower tile pairs (it, jt <= it); a wave owns pairs wid and wid + 8)
     {
       const int npair = JT * (JT + 1) / 2;
       int pit[2], pjt[2];
@@ -626,40 +615,31 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
       }
       const bool has0 = wid < npair, has1 = wid + 8 < npair;
       d4 c0 = (d4){0.0, 0.0, 0.0, 0.0}, c1 = (d4){0.0, 0.0, 0.0, 0.0};
-      double tp[(80 * RF_KC) / BM_NT];   // T's next chunk: entry (row i = idx >> 5, chain row k0 + (idx & 31)), idx = tid + BM_NT e
-      auto loadT = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < (80 * RF_KC) / BM_NT; ++e) {
-          const int idx = tid + BM_NT * e, i = idx >> 5, k = k0 + (idx & 31);
-          tp[e] = (i < m && k < P) ? -pu[(size_t)i * ld + k] * rinv[i] : 0.0;
-        }
-      };
-      loadT(0);
       const int nch = (P + RF_KC - 1) / RF_KC;
       for (int c = 0; c < nch; ++c) {
-        double *Tc = work + (size_t)(c & 1) * RF_BUF, *Kc = Tc + 80 * RF_LDA;
+        double *Vc = work + (size_t)(c & 1) * RF_BUF;
         const int k0 = c * RF_KC;
 #pragma unroll
-        for (int e = 0; e < (80 * RF_KC) / BM_NT; ++e) {
-          const int idx = tid + BM_NT * e;
-          Tc[(idx >> 5) * RF_LDA + (idx & 31)] = tp[e];
-        }
-        if (c + 1 < nch) loadT(k0 + RF_KC);   // in flight under the covariance arithmetic and the MFMAs
-        if (qn == 1) rf_cov_chunk<false>(Kc, s_cpt, qn, s2, nphi, sx, sy, smv, P, m, k0, tid);
-        else rf_cov_chunk<true>(Kc, s_cpt, qn, s2, nphi, sx, sy, smv, P, m, k0, tid);
+        for (int e = 0; e < RF_BUF / BM_NT; ++e) Vc[tid + BM_NT * e] = vp[e];
+        if (c + 1 < nch) loadV(k0 + RF_KC);   // in flight under the MFMAs
         __syncthreads();   // one barrier per chunk: the buffer written next was last read two chunks ago
         const int ns = min(RF_KC / 4, (P - k0 + 3) >> 2);
-        if (has0) {
-          const double *ap = Tc + (pit[0] * 16 + l15) * RF_LDA + l4, *bp = Kc + l4 * RF_LDB + pjt[0] * 16 + l15;
+        const double *ap0 = Vc + l4 * RF_LDB + pit[0] * 16 + l15, *bp0 = Vc + l4 * RF_LDB + pjt[0] * 16 + l15;
+        const double *ap1 = Vc + l4 * RF_LDB + pit[1] * 16 + l15, *bp1 = Vc + l4 * RF_LDB + pjt[1] * 16 + l15;
+        if (ns == RF_KC / 4) {
+          if (has0) {
 #pragma unroll
-          for (int s = 0; s < RF_KC / 4; ++s)
-            if (s < ns) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s], bp[4 * s * RF_LDB], c0, 0, 0, 0);
-        }
-        if (has1) {
-          const double *ap = Tc + (pit[1] * 16 + l15) * RF_LDA + l4, *bp = Kc + l4 * RF_LDB + pjt[1] * 16 + l15;
+            for (int s = 0; s < RF_KC / 4; ++s) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap0[4 * s * RF_LDB], bp0[4 * s * RF_LDB], c0, 0, 0, 0);
+          }
+          if (has1) {
 #pragma unroll
-          for (int s = 0; s < RF_KC / 4; ++s)
-            if (s < ns) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * s], bp[4 * s * RF_LDB], c1, 0, 0, 0);
+            for (int s = 0; s < RF_KC / 4; ++s) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap1[4 * s * RF_LDB], bp1[4 * s * RF_LDB], c1, 0, 0, 0);
+          }
+        } else {   // the chain's last rows (rows beyond it are zero in the buffer)
+          for (int s = 0; s < ns; ++s) {
+            if (has0) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap0[4 * s * RF_LDB], bp0[4 * s * RF_LDB], c0, 0, 0, 0);
+            if (has1) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap1[4 * s * RF_LDB], bp1[4 * s * RF_LDB], c1, 0, 0, 0);
+          }
         }
       }
       __syncthreads();   // the staging buffers are done with: R takes their place
@@ -673,8 +653,8 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
           for (int r = 0; r < 4; ++r) {
             const int i = pit[h2] * 16 + l4 + 4 * r, j = pjt[h2] * 16 + l15;
             if (i < m && j <= i) {
-              const double kij = qn == 1 ? lc_cov<false>(s_cpt, qn, s2, nphi, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j])
-                                         : lc_cov<true>(s_cpt, qn, s2, nphi, sx[P + i], sy[P + i], smv[P + i], sx[P + j], sy[P + j], smv[P + j]);
+              const double kij = qn == 1 ? lc_cov<false>(s_cpt, qn, s2, nphi, sx[i], sy[i], smv[i], sx[j], sy[j], smv[j])
+                                         : lc_cov<true>(s_cpt, qn, s2, nphi, sx[i], sy[i], smv[i], sx[j], sy[j], smv[j]);
               Rl[i * m + j] = kij - c[r];
             }
           }
@@ -686,21 +666,16 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
     block_chol_invert_mfma(Rl, Ril, m, &s_fail);
     STAMP(3);
     // ---- panel <- -Ri T in place: wave w owns chain column blocks kt = w, w + 8, ...; it holds the block's T entries (all rows of
-    // the unit: <= 80 = 20 K-steps) in registers before any of them is overwritten.  N w_pa rides along.
+    // the unit: <= 80 = 20 K-steps) in registers before any of them is overwritten
     {
       const int nkt = (P + 15) >> 4, njs = (m + 3) >> 2;
-      double hvp[5][4];
-#pragma unroll
-      for (int it = 0; it < 5; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hvp[it][r] = 0.0;
       double tn[20];   // B operands of the wave's NEXT column block: T[j = 4 s + l4][kb]
       auto loadTb = [&](int kt) {
         const int kb = kt * 16 + l15;
 #pragma unroll
         for (int s2 = 0; s2 < 20; ++s2) {
           const int j = 4 * s2 + l4;
-          tn[s2] = (s2 < njs && j < m && kb < P) ? -pu[(size_t)j * ld + kb] * rinv[min(j, m - 1)] : 0.0;
+          tn[s2] = (s2 < njs && j < m && kb < P) ? pu[(size_t)j * ld + kb] : 0.0;   // raw: scaled below, one round later
         }
       };
       if (wid < nkt) loadTb(wid);
@@ -708,9 +683,8 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
         const int kb = kt * 16 + l15;
         double tb[20];
 #pragma unroll
-        for (int s2 = 0; s2 < 20; ++s2) tb[s2] = tn[s2];
+        for (int s2 = 0; s2 < 20; ++s2) tb[s2] = -tn[s2] * rinv[min(4 * s2 + l4, m - 1)];
         if (kt + BM_NT / 64 < nkt) loadTb(kt + BM_NT / 64);   // another column block: no entry of it is written by this round
-        const double wk = kb < P ? wv[kb] : 0.0;
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
           if (it < JT) {
@@ -718,9 +692,11 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
             d4 c = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s2 = 0; s2 < 20; ++s2) {
-              if (s2 < njs && 4 * s2 < it * 16 + 16) {   // Ri is lower triangular: row tile `it` needs columns < 16 (it + 1)
+              if (4 * s2 < it * 16 + 16) {   // (compile time) Ri is lower triangular: row tile `it` needs columns < 16 (it + 1); rows of T
+                                             // beyond the block are zero operands: no run-time guard, the MFMAs of a tile are one basic block
                 const int j = 4 * s2 + l4;
-                const double a1 = (ia < m && j <= ia) ? -Ril[ia * m + j] : 0.0;
+                const double a0 = Ril[min(ia, m - 1) * m + min(j, m - 1)];
+                const double a1 = (ia < m && j <= ia) ? -a0 : 0.0;
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, tb[s2], c, 0, 0, 0);
               }
             }
@@ -728,39 +704,20 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
             for (int r = 0; r < 4; ++r) {
               const int i = it * 16 + l4 + 4 * r;
               if (i < m && kb < P) pu[(size_t)i * ld + kb] = c[r];
-              hvp[it][r] = fma(c[r], wk, hvp[it][r]);
             }
           }
         }
       }
-      // (N w_pa)[i] = sum over the chain columns: this wave's share, summed over its 16 column lanes
-#pragma unroll
-      for (int it = 0; it < 5; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double x = hvp[it][r];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
-          const int i = it * 16 + l4 + 4 * r;
-          if (l15 == 0 && i < m) hp[wid * maxM + i] = x;
-        }
     }
-    __syncthreads();
     STAMP(4);
-    for (int i = tid; i < m; i += BM_NT) {
-      double a = 0.0;
-      for (int w8 = 0; w8 < BM_NT / 64; ++w8) a += hp[w8 * maxM + i];
-      hv[i] = a;   // = N w_pa
-    }
     for (int idx = tid; idx < m * m; idx += BM_NT) {
       const int i = idx / m, j = idx - i * m;
       pu[(size_t)i * ld + P + j] = (j <= i) ? Ril[idx] : 0.0;
     }
-    __syncthreads();
     double wcore_part = 0.0, logdet_part = 0.0;
-    for (int i = tid; i < m; i += BM_NT) {   // e = Ri w_u + N w_pa
-      double acc = hv[i];
-      for (int j = 0; j <= i; ++j) acc += Ril[i * m + j] * wv[P + j];
+    for (int i = tid; i < m; i += BM_NT) {   // e = Ri (w_u - T w_pa)
+      double acc = 0.0;
+      for (int j = 0; j <= i; ++j) acc += Ril[i * m + j] * (wv[j] - hv[j]);
       wcore_part += acc * acc;
       logdet_part += log(Ril[i * m + i]);
     }
