@@ -14,7 +14,7 @@ _lib.LIB_PATH = os.path.join(ROOT, "profiles", "micro", "libspamtree_hip_stamps.
 from spamtree_amd.model import SpamTreeMV  # noqa: E402
 from spamtree_amd.synthetic import make_workload  # noqa: E402
 
-NAMES = {0: "topology + coords + 1 / r", 2: "Schur: T chunk + covariance chunk -> LDS, MFMA", 3: "cholesky + inverse",
+NAMES = {0: "topology + coords + 1 / r", 2: "Schur: V chunks -> LDS, MFMA", 3: "cholesky + inverse",
          4: "N = -Ri T in place (MFMA) + N w_pa", 5: "Ri out + scalars"}
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 577
 wl = make_workload(side, q=3)

@@ -19,9 +19,8 @@ struct FactorArgs {
   double *scratch;      // BIG
   long long scratch_stride;
   int maxP, maxM, maxMa, SR;
-  const double *vscr;     // k_factor_ref_finish: V = Linv_pa K_pa,u as k_factor_lchain left it (row-major per sibling group) ...
-  const long long *voff;  // ... per block of the list: where its first column starts ...
-  const int *vld;         // ... and the group's row stride
+  const double *vscr;     // k_factor_ref_finish: V = Linv_pa K_pa,u as k_factor_lchain left it (row-major per block, row stride RF_LDB) ...
+  const long long *voff;  // ... per block of the list: where its matrix starts ...
   const double *hvrow;    // ... per device row: (T w_pa)_j as k_factor_lchain summed it
 };
 

@@ -42,8 +42,9 @@ struct LcSlab {
   long long row0;   // first device row (column) of the slab
   long long pan0;   // panel arena offset of that row's panel row (rows of the group follow each other with stride ld)
   int blk0;         // a block of the group: chain, level
-  int ncol, ld, ldv;
-  long long vs0;    // reference levels: where the slab's first column starts in the V scratch (row stride ldv = the group's columns)
+  int ncol, ld, vcol0;
+  long long vs0;    // reference levels: the V scratch of the group's first block (the blocks' matrices follow each other); vcol0 = the
+                    // slab's first column counted over the group (blocks of a group are equally wide)
 };
 
 struct LcArgs {
@@ -64,18 +65,21 @@ struct LcArgs {
 };
 
 // k_factor_ref_finish (second half of a REFERENCE level on this route): the Schur complement R = K_uu - V'V walks the chain in
-// chunks of RF_KC rows of V (left in a scratch by k_factor_lchain) staged in LDS, in two buffers that overlay R / Ri (free until
-// the product is complete)
-#define RF_KC 64
-#define RF_LDB 80    // row stride of a staged chunk: 80 = 16 mod 32 (the four K rows of an operand fall into alternate bank halves)
-#define RF_BUF (RF_KC * RF_LDB)
+// chunks of RF_KC rows of V.  k_factor_lchain leaves V per block as a [P rounded up to 4][RF_LDB] row-major matrix in a scratch, so
+// that a chunk is ONE contiguous run that LDS-DMA copies verbatim (no registers, no LDS stores) into a ring of RF_NBUF buffers
+// overlaid on R / Ri (free until the product is complete): three chunks are in flight while one is multiplied.
+#define RF_KC 32
+#define RF_LDB 80      // row stride of V in the scratch and in LDS: 80 = 16 mod 32 (the four K rows of an operand fall into alternate bank halves)
+#define RF_NBUF 4
+#define RF_BUFD 3072   // doubles per buffer: 24 pieces of 1 KB = three per wave (the chunk's 20 KB and the first rows of the next one)
 __host__ __device__ constexpr size_t rf_work_doubles(int maxM) {
-  const size_t a = (size_t)2 * maxM * maxM, b = (size_t)2 * RF_BUF;
+  const size_t a = (size_t)2 * maxM * maxM, b = (size_t)RF_NBUF * RF_BUFD;
   return a > b ? a : b;
 }
 __host__ __device__ constexpr size_t rf_lds_bytes(int maxM) {   // w, x, y, T w_pa, 1 / r of the block | work | outcome ids
   return (5 * (size_t)maxM + rf_work_doubles(maxM)) * 8 + (size_t)((maxM + 1) & ~1) * 4 + 64;
 }
+__host__ __device__ constexpr long long rf_vsize(int P) { return (long long)((P + 3) & ~3) * RF_LDB; }   // a block's V in the scratch (doubles)
 
 #ifdef ST_DEFS_FACTOR_WIDE
 template <bool MV>
@@ -396,11 +400,13 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
       }
     }
     lds_barrier();   // phase 2 reuses the buffers
-    if (A.vscr && cok) {   // reference level: V (the B-operand layout: kx[st] = V[4 st + l4][column]) for k_factor_ref_finish
-      double *vp = A.vscr + S.vs0 + jc + (size_t)l4 * S.ldv;
+    if (A.vscr && cok) {   // reference level: V (the B-operand layout: kx[st] = V[4 st + l4][column]) for k_factor_ref_finish; rows up
+                           // to the next multiple of four are exact zeros and are written too (its last K-step reads them)
+      const int gcol = S.vcol0 + jc, bi = gcol / B.m;
+      double *vp = A.vscr + S.vs0 + bi * rf_vsize(P) + (gcol - bi * B.m) + (size_t)l4 * RF_LDB;
 #pragma unroll
       for (int st = 0; st < NKX; ++st)
-        if (4 * st + l4 < P) vp[(size_t)4 * st * S.ldv] = kx[st];
+        if (4 * st < P) vp[(size_t)4 * st * RF_LDB] = kx[st];
     }
     STAMP(6);
 
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
   __shared__ int s_fail;
   __shared__ double s_red[BM_NT / 64];
   __shared__ double s_cpt[3 * QMAX * QMAX + QMAX];
-  static_assert(RF_BUF % BM_NT == 0, "chunk shape");
+  static_assert(RF_BUFD == (BM_NT / 64) * 3 * 128 && RF_BUFD >= RF_KC * RF_LDB && (RF_NBUF & (RF_NBUF - 1)) == 0, "chunk shape");
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int maxM = A.maxM;
@@ -580,20 +586,22 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
     const int JT = (m + 15) >> 4;
     double *pu = A.panels + B.panel_off;
     const double *Vb = A.vscr + A.voff[li];
-    const int ldv = A.vld[li];
     st_level = B.level;
     __syncthreads();
     if (tid == 0) s_fail = 0;
-    // V's first chunk is requested before anything else: entry (chain row k0 + idx / 80, column idx % 80), idx = tid + BM_NT e
-    double vp[RF_BUF / BM_NT];
-    auto loadV = [&](int k0) {
-#pragma unroll
-      for (int e = 0; e < RF_BUF / BM_NT; ++e) {
-        const int idx = tid + BM_NT * e, kk = idx / RF_LDB, j = idx - kk * RF_LDB, k = k0 + kk;
-        vp[e] = (j < m && k < P) ? Vb[(size_t)k * ldv + j] : 0.0;
-      }
+    // V's first chunks are requested before anything else.  Chunk c = rows [RF_KC c, RF_KC (c + 1)) = one contiguous run of the
+    // block's V; wave w moves pieces 3 w .. 3 w + 2 of 1 KB (one address, immediate offsets)
+    const int nch = (P + RF_KC - 1) / RF_KC;
+    auto dmaV = [&](int c) {
+      const double *src = Vb + (size_t)c * (RF_KC * RF_LDB) + wid * 384 + 2 * lane;
+      q_lds_void *dst = (q_lds_void *)(work + (size_t)(c & (RF_NBUF - 1)) * RF_BUFD + wid * 384);
+      __builtin_amdgcn_global_load_lds((q_glb_void *)src, dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((q_glb_void *)src, dst, 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((q_glb_void *)src, dst, 16, 2048, 0);
     };
-    loadV(0);
+#pragma unroll
+    for (int c = 0; c < RF_NBUF - 1; ++c)
+      if (c < nch) dmaV(c);
     __syncthreads();
     for (int i = tid; i < m; i += BM_NT) {
       sx[i] = A.cx[B.row0 + i]; sy[i] = A.cy[B.row0 + i]; smv[i] = A.mv[B.row0 + i]; wv[i] = A.w_in[B.row0 + i]; hv[i] = A.hvrow[B.row0 + i];
@@ -615,15 +623,15 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
       }
       const bool has0 = wid < npair, has1 = wid + 8 < npair;
       d4 c0 = (d4){0.0, 0.0, 0.0, 0.0}, c1 = (d4){0.0, 0.0, 0.0, 0.0};
-      const int nch = (P + RF_KC - 1) / RF_KC;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the block's own vectors above (the waits below count this wave's DMA only)
       for (int c = 0; c < nch; ++c) {
-        double *Vc = work + (size_t)(c & 1) * RF_BUF;
-        const int k0 = c * RF_KC;
-#pragma unroll
-        for (int e = 0; e < RF_BUF / BM_NT; ++e) Vc[tid + BM_NT * e] = vp[e];
-        if (c + 1 < nch) loadV(k0 + RF_KC);   // in flight under the MFMAs
-        __syncthreads();   // one barrier per chunk: the buffer written next was last read two chunks ago
-        const int ns = min(RF_KC / 4, (P - k0 + 3) >> 2);
+        const double *Vc = work + (size_t)(c & (RF_NBUF - 1)) * RF_BUFD;
+        // this wave's pieces of chunk c have landed: the two younger chunks (three instructions each) may still be in flight
+        if (c + RF_NBUF - 2 < nch) __builtin_amdgcn_s_waitcnt(0x0F76);        // vmcnt(6)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the chain's tail
+        lds_barrier();   // ... and everybody else's; everybody is done with chunk c - 1, whose buffer chunk c + 3 takes
+        if (c + RF_NBUF - 1 < nch) dmaV(c + RF_NBUF - 1);
+        const int ns = min(RF_KC / 4, (P - RF_KC * c + 3) >> 2);
         const double *ap0 = Vc + l4 * RF_LDB + pit[0] * 16 + l15, *bp0 = Vc + l4 * RF_LDB + pjt[0] * 16 + l15;
         const double *ap1 = Vc + l4 * RF_LDB + pit[1] * 16 + l15, *bp1 = Vc + l4 * RF_LDB + pjt[1] * 16 + l15;
         if (ns == RF_KC / 4) {
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
 #pragma unroll
             for (int s = 0; s < RF_KC / 4; ++s) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap1[4 * s * RF_LDB], bp1[4 * s * RF_LDB], c1, 0, 0, 0);
           }
-        } else {   // the chain's last rows (rows beyond it are zero in the buffer)
+        } else {   // the chain's last rows (whole K-steps only: V's rows up to the next multiple of four are zeros)
           for (int s = 0; s < ns; ++s) {
             if (has0) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap0[4 * s * RF_LDB], bp0[4 * s * RF_LDB], c0, 0, 0, 0);
             if (has1) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap1[4 * s * RF_LDB], bp1[4 * s * RF_LDB], c1, 0, 0, 0);

@@ -108,8 +108,8 @@ struct st_handle_s {
   int wide_on = 1;                            // SPAMTREE_WIDE=0: k_factor_bigmfma (one block per workgroup) instead
   std::vector<LcSlab> lcslabs;                // k_factor_lchain: slabs of sibling groups
   DevBuf<LcSlab> d_lcslabs;
-  std::vector<long long> rfvoff; std::vector<int> rfvld;   // k_factor_ref_finish: per block of a reference level on the lchain route, its columns in the V scratch
-  DevBuf<long long> d_rfvoff; DevBuf<int> d_rfvld;
+  std::vector<long long> rfvoff;   // k_factor_ref_finish: per block of a reference level on the lchain route, its columns in the V scratch
+  DevBuf<long long> d_rfvoff;
   DevBuf<double> d_vscr;                      // V = Linv_pa K_pa,u of ONE such level (the largest): written by k_factor_lchain, read by k_factor_ref_finish
   size_t vscr_need = 0;
   DevBuf<double> d_lcrow;                     // per-row e^2 | log r of the lchain levels (2 n)
@@ -301,7 +301,7 @@ extern "C" int st_destroy(st_handle h) {
   for (int s = 0; s < 2; ++s) { h->d_logdet[s].free(); h->d_loglik[s].free(); }
   h->d_scalars.free(); h->d_partial.free(); h->d_stats.free(); h->d_scratch.free(); h->d_tmp_n.free(); h->d_tsq.free();
   h->d_mv.free(); h->d_anc.free(); h->d_dch.free(); h->d_lvl.free(); h->d_pred.free(); h->d_allobs.free(); h->d_err.free();
-  h->d_twin.free(); h->d_wgrps.free(); h->d_lcslabs.free(); h->d_lcrow.free(); h->d_rfvoff.free(); h->d_rfvld.free(); h->d_vscr.free(); h->d_s0.free(); h->d_s0off.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
+  h->d_twin.free(); h->d_wgrps.free(); h->d_lcslabs.free(); h->d_lcrow.free(); h->d_rfvoff.free(); h->d_vscr.free(); h->d_s0.free(); h->d_s0off.free(); h->d_obs.free(); h->d_dev2model.free(); h->d_partner.free(); h->d_blks.free(); h->d_grps.free(); h->d_quads.free(); h->d_gdesc.free();
   h->d_ownobs.free(); h->d_owngrp.free(); h->d_ownslow.free(); h->d_rowmask.free(); h->d_blkmask.free(); h->d_comm.free(); h->d_gather.free(); h->d_gidx.free(); h->d_gerr.free(); h->d_err2.free(); h->d_toplist.free();
   if (h->ev_top) (void)hipEventDestroy(h->ev_top);
   if (h->ev_main) (void)hipEventDestroy(h->ev_main);
@@ -803,14 +803,12 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
         for (int s0 = 0; s0 < Ncols; s0 += 16 * tps) {
           LcSlab S;
           S.row0 = B0.row0 + s0; S.pan0 = B0.panel_off + (long long)s0 * B0.ld; S.blk0 = b0;
-          S.ncol = std::min(16 * tps, Ncols - s0); S.ld = B0.ld; S.ldv = Ncols; S.vs0 = vrun + s0;
+          S.ncol = std::min(16 * tps, Ncols - s0); S.ld = B0.ld; S.vcol0 = s0; S.vs0 = vrun;
           h->lcslabs.push_back(S);
           ++L.lc_count;
         }
-        if (L.lchain_ref) {
-          int co = 0;
-          for (int i = 0; i < cnt; ++i) { h->rfvoff.push_back(vrun + co); h->rfvld.push_back(Ncols); co += h->blks[b0 + i].m; }
-          vrun += (long long)B0.P * Ncols;
+        if (L.lchain_ref) {   // the group's blocks are equally wide (same P and ld): block i of the group owns columns [i m, (i + 1) m)
+          for (int i = 0; i < cnt; ++i) { h->rfvoff.push_back(vrun); vrun += rf_vsize(B0.P); }
         }
         k += cnt;
       }
@@ -1097,7 +1095,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   { std::vector<Quad> g = h->quads; if (g.empty()) g.push_back(Quad{0, 0, 0, 0}); CCHK(h->d_quads.upload(g)); }
   { std::vector<WideGrp> g = h->wgrps; if (g.empty()) g.push_back(WideGrp{0, 0}); CCHK(h->d_wgrps.upload(g)); }
   if (!h->lcslabs.empty()) { CCHK(h->d_lcslabs.upload(h->lcslabs)); CCHK(h->d_lcrow.alloc((size_t)2 * h->n_all)); }
-  if (!h->rfvoff.empty()) { CCHK(h->d_rfvoff.upload(h->rfvoff)); CCHK(h->d_rfvld.upload(h->rfvld)); CCHK(h->d_vscr.alloc(h->vscr_need + 16)); }
+  if (!h->rfvoff.empty()) { CCHK(h->d_rfvoff.upload(h->rfvoff)); CCHK(h->d_vscr.alloc(h->vscr_need + (size_t)2 * RF_BUFD)); }   // (+ what a chunk's DMA reads past the last block)
   {
     std::vector<long long> s0off((size_t)(nb > 0 ? nb : 1), -1);
     size_t tot = 0;
@@ -1516,7 +1514,7 @@ static int factor_launch(st_handle h, int phys, const CovPar &cp, int g_lo = 0, 
         if (L.lchain == 96) hipLaunchKernelGGL((k_factor_lchain<96>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(96) * 8, st, C, cp);
         else hipLaunchKernelGGL((k_factor_lchain<136>), dim3(L.lc_count), dim3(LC_NT), lc_dyn_doubles(136) * 8, st, C, cp);
         if (L.lchain_ref) {   // the panels hold [ -r_j T_j | r_j ] per column: finish the blocks (Schur complement, factorisation, -Ri T in place)
-          A.vscr = h->d_vscr.p; A.voff = h->d_rfvoff.p + L.rf_first; A.vld = h->d_rfvld.p + L.rf_first; A.hvrow = h->d_lcrow.p;
+          A.vscr = h->d_vscr.p; A.voff = h->d_rfvoff.p + L.rf_first; A.hvrow = h->d_lcrow.p;
           hipLaunchKernelGGL(k_factor_ref_finish, dim3(std::min(A.nlist, 2 * h->sm_count)), dim3(BM_NT), L.lds_ref_finish, st, A, cp);
         } else
         hipLaunchKernelGGL(k_lchain_scalars, dim3((A.nlist + 255) / 256), dim3(256), 0, st, h->d_blks.p, A.list, A.nlist, h->d_lcrow.p, h->n_all,
