@@ -674,48 +674,67 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
     block_chol_invert_mfma(Rl, Ril, m, &s_fail);
     STAMP(3);
     // ---- panel <- -Ri T in place: wave w owns chain column blocks kt = w, w + 8, ...; it holds the block's T entries (all rows of
-    // the unit: <= 80 = 20 K-steps) in registers before any of them is overwritten
+    // the unit: <= 80 = 20 K-steps) in registers before any of them is overwritten.  The next column block's entries are requested
+    // before the current block's MFMAs and stores, and the wait for them one round later must not wait for those stores as well
+    // (vmcnt counts loads and stores in issue order; measured: 37 % of the kernel when it was vmcnt(0)).  The compiler emits the
+    // partial wait only if it can COUNT the younger operations on every path into the loop header, so the five-tile form (blocks of
+    // 65-80 rows: the default multivariate tree) has no branch around a memory operation: loads take clamped addresses, every
+    // lane stores exactly four values per row tile (lanes outside the block into the block's V scratch, which the Schur product
+    // has consumed), and the last round requests its own block once more (the first round's wait is the loop's peeled prologue).
     {
-      const int nkt = (P + 15) >> 4, njs = (m + 3) >> 2;
-      double tn[20];   // B operands of the wave's NEXT column block: T[j = 4 s + l4][kb]
-      auto loadTb = [&](int kt) {
-        const int kb = kt * 16 + l15;
+      const int nkt = (P + 15) >> 4;
+      double *dump = const_cast<double *>(Vb) + tid;
+      auto apply = [&](auto fullc) {
+        constexpr bool FULL = decltype(fullc)::value;
+        double tn[20];   // B operands of the wave's NEXT column block: T[j = 4 s + l4][kb], raw panel entries
+        auto loadTb = [&](int kt) {
+          const int kbc = min(kt * 16 + l15, P - 1);
 #pragma unroll
-        for (int s2 = 0; s2 < 20; ++s2) {
-          const int j = 4 * s2 + l4;
-          tn[s2] = (s2 < njs && j < m && kb < P) ? pu[(size_t)j * ld + kb] : 0.0;   // raw: scaled below, one round later
-        }
-      };
-      if (wid < nkt) loadTb(wid);
-      for (int kt = wid; kt < nkt; kt += BM_NT / 64) {
-        const int kb = kt * 16 + l15;
-        double tb[20];
+          for (int s2 = 0; s2 < 20; ++s2) tn[s2] = pu[(size_t)min(4 * s2 + l4, m - 1) * ld + kbc];
+        };
+        if (wid >= nkt) return;
+        loadTb(wid);
+        for (int kt = wid; kt < nkt; kt += BM_NT / 64) {
+          const int kb = kt * 16 + l15;
+          double tb[20];
 #pragma unroll
-        for (int s2 = 0; s2 < 20; ++s2) tb[s2] = -tn[s2] * rinv[min(4 * s2 + l4, m - 1)];
-        if (kt + BM_NT / 64 < nkt) loadTb(kt + BM_NT / 64);   // another column block: no entry of it is written by this round
+          for (int s2 = 0; s2 < 20; ++s2) {
+            const double rv = rinv[min(4 * s2 + l4, m - 1)];   // (read by every lane: no branch around it)
+            tb[s2] = (4 * s2 + l4 < m && kb < P) ? -tn[s2] * rv : 0.0;
+          }
+          if constexpr (FULL) loadTb(min(kt + BM_NT / 64, nkt - 1));
+          else if (kt + BM_NT / 64 < nkt) loadTb(kt + BM_NT / 64);   // another column block: no entry of it is written by this round
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-          if (it < JT) {
-            const int ia = it * 16 + l15;
-            d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+          for (int it = 0; it < 5; ++it) {
+            if (FULL || it < JT) {
+              const int ia = it * 16 + l15;
+              d4 c = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s2 = 0; s2 < 20; ++s2) {
-              if (4 * s2 < it * 16 + 16) {   // (compile time) Ri is lower triangular: row tile `it` needs columns < 16 (it + 1); rows of T
-                                             // beyond the block are zero operands: no run-time guard, the MFMAs of a tile are one basic block
-                const int j = 4 * s2 + l4;
-                const double a0 = Ril[min(ia, m - 1) * m + min(j, m - 1)];
-                const double a1 = (ia < m && j <= ia) ? -a0 : 0.0;
-                c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, tb[s2], c, 0, 0, 0);
+              for (int s2 = 0; s2 < 20; ++s2) {
+                if (4 * s2 < it * 16 + 16) {   // (compile time) Ri is lower triangular: row tile `it` needs columns < 16 (it + 1); rows of
+                                               // T beyond the block are zero operands: no run-time guard, a tile's MFMAs are one basic block
+                  const int j = 4 * s2 + l4;
+                  const double a0 = Ril[min(ia, m - 1) * m + min(j, m - 1)];
+                  const double a1 = (ia < m && j <= ia) ? -a0 : 0.0;
+                  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, tb[s2], c, 0, 0, 0);
+                }
               }
-            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = it * 16 + l4 + 4 * r;
-              if (i < m && kb < P) pu[(size_t)i * ld + kb] = c[r];
+              for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + l4 + 4 * r;
+                if constexpr (FULL) {
+                  double *dst = (i < m && kb < P) ? pu + (size_t)i * ld + kb : dump;
+                  *dst = c[r];
+                } else {
+                  if (i < m && kb < P) pu[(size_t)i * ld + kb] = c[r];
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0);   // a row tile at a time
             }
           }
         }
-      }
+      };
+      if (JT == 5) apply(std::true_type{}); else apply(std::false_type{});
     }
     STAMP(4);
     for (int idx = tid; idx < m * m; idx += BM_NT) {
