@@ -24,6 +24,11 @@
 #define LC_RSH 17
 #endif
 // LC_RSH: phase 1: tiles up to this index are staged by all four waves (above: by the loader waves alone)
+#ifndef LC_G
+#define LC_G 2
+#endif
+// LC_G: phase 2 takes its row tiles in groups of LC_G (one compare + branch + operand hand-over per group instead of per tile); a
+// group that starts above the column block's diagonal tile multiplies the rows in between by zeros the loader put there
 
 __host__ __device__ constexpr int lc_lds_stride(int nkx) {   // phase-1 row stride: >= 4 nkx + 24, 2 x odd (conflict-free A reads)
   int s = 4 * nkx + 24;
@@ -82,16 +87,24 @@ __host__ __device__ constexpr size_t rf_lds_bytes(int maxM) {   // w, x, y, T w_
 __host__ __device__ constexpr long long rf_vsize(int P) { return (long long)((P + 3) & ~3) * RF_LDB; }   // a block's V in the scratch (doubles)
 
 #ifdef ST_DEFS_FACTOR_WIDE
+#define LC_CPT (3 * QMAX * QMAX + QMAX + 64)   // the table: rate | amp | amp2 per outcome pair, phi per outcome, 2^(j/64) for cov_exp_tab
 template <bool MV>
 __device__ __forceinline__ double lc_cov(const double *tab, int q, double s2, double nphi, double xi, double yi, int vi, double xj, double yj, int vj) {
   const double dx = xi - xj, dy = yi - yj;
   const double h = cov_sqrt(dx * dx + dy * dy);
-  if constexpr (!MV) return s2 * cov_exp(nphi * h);
+  const double *e64 = tab + 3 * QMAX * QMAX + QMAX;
+  if constexpr (!MV) return s2 * cov_exp_tab(nphi * h, e64);
   const int ij = vi * q + vj;
-  const double r = tab[QMAX * QMAX + ij] * cov_exp(-tab[ij] * h);
+  const double r = tab[QMAX * QMAX + ij] * cov_exp_tab(-tab[ij] * h, e64);
   const double a2 = tab[2 * QMAX * QMAX + ij];
-  const double e2 = cov_exp(-tab[3 * QMAX * QMAX + vi] * h);
+  const double e2 = cov_exp_tab(-tab[3 * QMAX * QMAX + vi] * h, e64);
   return a2 != 0.0 ? fma(a2, e2, r) : r;   // (a select, not a branch; r + a2 e2 rounds as the reference's sum does)
+}
+__device__ __forceinline__ void lc_cov_table(double *tab, const CovPar &cp, int tid, int nt) {
+  for (int i = tid; i < LC_CPT; i += nt) {
+    const int a = i / (QMAX * QMAX), ij = i - a * (QMAX * QMAX);
+    tab[i] = i >= 3 * QMAX * QMAX + QMAX ? EXP2_64[i - (3 * QMAX * QMAX + QMAX)] : (a == 0 ? cp.rate[ij] : (a == 1 ? cp.amp[ij] : (a == 2 ? cp.amp2[ij] : cp.phi[ij])));
+  }
 }
 
 // A workgroup's columns: a SLAB of a sibling group -- up to 64 consecutive columns of the concatenated rows of consecutive
@@ -118,13 +131,14 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
   constexpr int KH = (B1 - (5 * PMAX) / 2 - 8) / 256;   // covariance scratch: K-steps per pass ([KH][64] doubles per wave)
   constexpr int NPASS = (NKX + KH - 1) / KH;
   static_assert(KH >= 8, "covariance scratch too small");
+  static_assert(NTMAX % LC_G == 0, "phase 2 takes its row tiles in whole groups");
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ], s_apan[MAXJ];
   __shared__ double s_wpa[PMAX];
   __shared__ long long s_rsrc[PMAX];   // chain row c: where it starts in the panel arena ...
   __shared__ int s_rlen[PMAX];         // ... and its length (entries up to the end of its own ancestor's rows)
-  __shared__ double s_cpt[3 * QMAX * QMAX + QMAX];   // rate, amp, amp2 per outcome pair, phi per outcome: the covariance pass reads
+  __shared__ double s_cpt[LC_CPT];   // rate, amp, amp2 per outcome pair, phi per outcome, the exp table: the covariance pass reads
                                                      // them from LDS (as kernel arguments indexed per lane they are global loads,
                                                      // one dependent round trip per entry with a single wave per SIMD)
   __shared__ int s_fail;
@@ -147,10 +161,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
     s_am[tid] = A.blks[a].m; s_arow[tid] = A.blks[a].row0; s_apan[tid] = A.blks[a].chain_off;
   }
   if (tid == 0) s_fail = 0;
-  for (int i = tid; i < 3 * QMAX * QMAX + QMAX; i += LC_NT) {
-    const int a = i / (QMAX * QMAX), ij = i - a * (QMAX * QMAX);
-    s_cpt[i] = a == 0 ? cp.rate[ij] : (a == 1 ? cp.amp[ij] : (a == 2 ? cp.amp2[ij] : cp.phi[ij]));
-  }
+  lc_cov_table(s_cpt, cp, tid, LC_NT);
   STAMP_DECL
   __syncthreads();
   if (tid == 0) {
@@ -255,6 +266,18 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
   double dacc = 0.0;   // sum_k V[k][column l15]^2 over this lane's rows
   double rj = 0.0, rq[4] = {0.0, 0.0, 0.0, 0.0};
   double h0 = 0.0, h1 = 0.0, h2 = 0.0, h3 = 0.0;   // hv = T w_pa for columns 4 q + l4, this lane's chain columns
+  // phase 2, LC_G > 1: the row tiles between the start of the diagonal tile's group and the diagonal tile itself (structural zeros of
+  // the factor's column block kt, not part of what is staged: the buffer holds an older block's rows there) are cleared by the
+  // loaders, 8-row group g by loader g % nload
+  auto zero_above = [&](int kt, double *buf) {
+    if (LC_G > 1) {
+      for (int g = 2 * (kt - kt % LC_G); g < 2 * kt; ++g)
+        if (lidx == g % nload) {
+          double *e = buf + (size_t)(8 * g + (lane >> 3)) * 16 + 2 * (lane & 7);
+          e[0] = 0.0; e[1] = 0.0;
+        }
+    }
+  };
   if (isload && JTb < 4) {
     // ---- a LOADER wave (no columns): both phases as ROLLED loops of their own -- it needs no static tile index -- that meet the
     // column waves at the same barriers.  What bounds a step is this wave's round trip (request, flight, padding), not the
@@ -353,6 +376,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
           if (j0 + 1 > i) e[1] = 0.0;
         }
       }
+      zero_above(kt, buf);
       lds_barrier();
       if (kt + 1 < NTL) fire2(kt + 1, lds + (size_t)(cur ^ 1) * B2);
       cur ^= 1;
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
               if (j0 + 1 > i) e[1] = 0.0;
             }
           }
+          zero_above(kt, buf);
         }
         STAMP(7);
         lds_barrier();
@@ -470,31 +495,32 @@ __global__ __launch_bounds__(LC_NT) void k_factor_lchain(LcArgs A, CovPar cp) {
           // the B operands of row tile r + 1 are requested BEFORE the MFMAs of row tile r (two register sets, taken in turn; a
           // scheduling barrier keeps the requests in front): every row tile is a basic block of its own (skipped for r < kt),
           // and the compiler neither moves loads across those nor hoists them above MFMAs that still read the same registers
-          double b0[4], b1[4];
-          if (kt & 1) {
+          double b0[4 * LC_G], b1[4 * LC_G];
+          const int r0 = kt - kt % LC_G;   // the group of the diagonal tile
+          if ((r0 / LC_G) & 1) {
   #pragma unroll
-            for (int q = 0; q < 4; ++q) { b1[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b0[q] = 0.0; }
+            for (int q = 0; q < 4 * LC_G; ++q) { b1[q] = bp[(size_t)(16 * r0 + 4 * q) * 16]; b0[q] = 0.0; }
           } else {
   #pragma unroll
-            for (int q = 0; q < 4; ++q) { b0[q] = bp[(size_t)(16 * kt + 4 * q) * 16]; b1[q] = 0.0; }
+            for (int q = 0; q < 4 * LC_G; ++q) { b0[q] = bp[(size_t)(16 * r0 + 4 * q) * 16]; b1[q] = 0.0; }
           }
   #pragma unroll
-          for (int r = 0; r < NTMAX; ++r) {
-            // (a computed entry -- switch (kt) with fall-through cases -- would save the compare + branch of every skipped tile,
+          for (int r = 0; r < NTMAX; r += LC_G) {
+            // (a computed entry -- switch (kt) with fall-through cases -- would save the compare + branch of every skipped group,
             // but the register allocator then needs > 512 VGPRs: measured, dropped)
-            if (r >= kt && r < NTL) {   // workgroup-uniform
-              __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this tile's operands (requested one tile ago) are here; said
+            if (r + LC_G - 1 >= kt && r < NTL) {   // workgroup-uniform
+              __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this group's operands (requested one group ago) are here; said
                                                     // explicitly (and visibly to the compiler), or it waits AFTER the new requests
-              if (r + 1 < NTMAX) {      // inside the buffer (B2 holds PMAX + 16 rows)
+              if (r + LC_G < NTMAX) {      // inside the buffer (B2 holds PMAX + 16 rows)
   #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  if ((r & 1) == 0) b1[q] = bp[(16 * (r + 1) + 4 * q) * 16]; else b0[q] = bp[(16 * (r + 1) + 4 * q) * 16];
+                for (int q = 0; q < 4 * LC_G; ++q) {
+                  if (((r / LC_G) & 1) == 0) b1[q] = bp[(16 * (r + LC_G) + 4 * q) * 16]; else b0[q] = bp[(16 * (r + LC_G) + 4 * q) * 16];
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
   #pragma unroll
-              for (int q = 0; q < 4; ++q)
-                if (4 * r + q < NKX) LCMFMA(kx[4 * r + q], (r & 1) == 0 ? b0[q] : b1[q], t);
+              for (int q = 0; q < 4 * LC_G; ++q)
+                if (4 * r + q < NKX) LCMFMA(kx[4 * r + q], ((r / LC_G) & 1) == 0 ? b0[q] : b1[q], t);
             }
           }
           const int k = 16 * kt + l15;
@@ -557,7 +583,7 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
   extern __shared__ double lds[];
   __shared__ int s_fail;
   __shared__ double s_red[BM_NT / 64];
-  __shared__ double s_cpt[3 * QMAX * QMAX + QMAX];
+  __shared__ double s_cpt[LC_CPT];
   static_assert(RF_BUFD == (BM_NT / 64) * 3 * 128 && RF_BUFD >= RF_KC * RF_LDB && (RF_NBUF & (RF_NBUF - 1)) == 0, "chunk shape");
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -571,10 +597,7 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
   double *Rl = work;
   double *Ril = Rl + (size_t)maxM * maxM;
   int *smv = (int *)(work + rf_work_doubles(maxM));
-  for (int i = tid; i < 3 * QMAX * QMAX + QMAX; i += BM_NT) {
-    const int a = i / (QMAX * QMAX), ij = i - a * (QMAX * QMAX);
-    s_cpt[i] = a == 0 ? cp.rate[ij] : (a == 1 ? cp.amp[ij] : (a == 2 ? cp.amp2[ij] : cp.phi[ij]));
-  }
+  lc_cov_table(s_cpt, cp, tid, BM_NT);
   const int qn = cp.q;
   const double s2 = cp.ai1[0], nphi = -cp.tmv[0];
   STAMP_DECL

@@ -504,19 +504,20 @@ __device__ __forceinline__ void wave_chol_eliminate(const double *Am, double *Bm
 }
 
 
-// wave_chol_eliminate for a 16 x 16 (or smaller) diagonal tile that sits inside a larger matrix: strides as parameters.
-//   Am: tile's first element, row stride lda, lower triangle valid.  Bm: receives L^{-1} (lower triangle), row stride ldb.
-//   mr <= 16 rows; rows >= mr behave as identity and are not written.  All 64 lanes must call.
-__device__ __forceinline__ void wave_chol_eliminate_tile(const double *Am, int lda, double *Bm, int ldb, int mr, int *fail, int lane) {
-  constexpr int MM = 16;
-  double a[MM], b[MM];
-  const bool row = lane < mr;
-  const int lr = min(lane, MM - 1);
+template <int J>
+__device__ __forceinline__ void fmac_bcast(double &d, const double src, const double f) {
+  // d += (lane J of this lane's 16-lane row: src) * f
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(f), "n"(J));
+}
+
+// Elimination of one diagonal tile (mr <= MM <= 16 rows) held in registers: a[j] = A[i][j] (j <= i, else 0; rows >= mr:
+// unit vectors), on return b[jj] = L^{-1}[i][4 jj + g] for lane 16 g + i.  Returns true in every lane when a pivot was not > 0.
+template <int MM>
+__device__ __forceinline__ bool dpp_tile_eliminate(double (&a)[MM], double (&b)[(MM + 3) / 4], int mr, int lane) {
+  constexpr int NB = (MM + 3) / 4;
+  const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-  for (int j = 0; j < MM; ++j) {
-    a[j] = (row && j <= lane) ? Am[(size_t)lr * lda + j] : (j == lane ? 1.0 : 0.0);
-    b[j] = j == lane ? 1.0 : 0.0;
-  }
+  for (int jj = 0; jj < NB; ++jj) b[jj] = (4 * jj + g == i) ? 1.0 : 0.0;
   double dd = 1.0;
   bool bad = false;
 #pragma unroll
@@ -524,24 +525,60 @@ __device__ __forceinline__ void wave_chol_eliminate_tile(const double *Am, int l
     if (k < mr) {   // wave-uniform
       const double d = readlane_f64(a[k], k);
       bad = bad || !(d > 0.0);
-      dd = lane == k ? d : dd;
+      dd = i == k ? d : dd;
       double rd = __builtin_amdgcn_rcp(d);
       rd = fma(fma(-d, rd, 1.0), rd, rd);
       rd = fma(fma(-d, rd, 1.0), rd, rd);
-      const double f = lane > k ? -a[k] * rd : 0.0;
-#pragma unroll
-      for (int j = k + 1; j < MM; ++j) a[j] = fma(f, readlane_f64(a[k], j), a[j]);
+      const double f = i > k ? -a[k] * rd : 0.0;
+      asm volatile("s_nop 1" ::: "memory");   // VALU write -> DPP read of the same VGPR needs two wait states; inline asm is not covered by the hazard recogniser
+      // A[i][j] -= A[i][k] A[j][k] / d   (lane j's a[k], row-broadcast)
 #pragma unroll
       for (int j = 0; j < MM; ++j)
-        if (j <= k) b[j] = fma(f, readlane_f64(b[j], k), b[j]);
+        if (j > k) {
+          switch (j) {   // j is a compile-time constant after unrolling: one case survives
+#define CA_CASE(J_) case J_: fmac_bcast<J_>(a[J_ < MM ? J_ : 0], a[k], f); break;
+            CA_CASE(1) CA_CASE(2) CA_CASE(3) CA_CASE(4) CA_CASE(5) CA_CASE(6) CA_CASE(7) CA_CASE(8)
+            CA_CASE(9) CA_CASE(10) CA_CASE(11) CA_CASE(12) CA_CASE(13) CA_CASE(14) CA_CASE(15)
+#undef CA_CASE
+          }
+        }
+      // B[i][c] -= (A[i][k] / d) B[k][c]   (lane k's b[jj]); row k of B is zero beyond column k
+#pragma unroll
+      for (int jj = 0; jj < NB; ++jj)
+        if (4 * jj <= k) {
+          switch (k) {   // k is a compile-time constant after unrolling: one case survives
+#define CB_CASE(K_) case K_: fmac_bcast<K_>(b[jj], b[jj], f); break;
+            CB_CASE(0) CB_CASE(1) CB_CASE(2) CB_CASE(3) CB_CASE(4) CB_CASE(5) CB_CASE(6) CB_CASE(7)
+            CB_CASE(8) CB_CASE(9) CB_CASE(10) CB_CASE(11) CB_CASE(12) CB_CASE(13) CB_CASE(14) CB_CASE(15)
+#undef CB_CASE
+          }
+        }
     }
   }
-  if (bad && lane == 0) *fail = 1;
   const double rs = rsqrt(dd);
-  if (row) {
 #pragma unroll
-    for (int j = 0; j < MM; ++j)
-      if (j <= lane) Bm[(size_t)lane * ldb + j] = b[j] * rs;
+  for (int jj = 0; jj < NB; ++jj) b[jj] *= rs;
+  return bad;
+}
+
+
+// Inverse Cholesky factor of a 16 x 16 (or smaller) diagonal tile that sits inside a larger matrix, by ONE wave (strides as parameters).
+//   Am: tile's first element, row stride lda, lower triangle valid.  Bm: receives L^{-1} (lower triangle), row stride ldb.
+//   mr <= 16 rows; rows >= mr behave as identity and are not written.  All 64 lanes must call.
+// Round 3: the DPP elimination of chol_blocked.hpp (row i in lane 16 g + i of all four lane rows, broadcasts as the DPP control of
+// a v_fmac_f64, each lane row a quarter of L^{-1}'s columns) instead of the v_readlane one: a third of the instructions, the same
+// arithmetic in the same order.
+__device__ __forceinline__ void wave_chol_eliminate_tile(const double *Am, int lda, double *Bm, int ldb, int mr, int *fail, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  double a[16], b[4];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = (i < mr && j <= i) ? Am[(size_t)i * lda + j] : (j == i ? 1.0 : 0.0);
+  const bool bad = dpp_tile_eliminate<16>(a, b, mr, lane);
+  if (bad && lane == 0) *fail = 1;
+  if (i < mr) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (4 * jj + g <= i) Bm[(size_t)i * ldb + 4 * jj + g] = b[jj];
   }
 }
 
