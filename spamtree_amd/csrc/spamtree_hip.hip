@@ -158,7 +158,7 @@ struct st_handle_s {
   int factor_gen = 1;
   int sample_lean = 1;                        // sweeps with cached Gram parts take k_sample_lean (SPAMTREE_SAMPLE_LEAN=0: never)
   int sample_wave = 1;                        // reference blocks of <= 27 rows: one block per wave (SPAMTREE_SAMPLE_WAVE=0: k_sample_lean)
-  int lchain_ref_on = 1, lchain_ref_min = 256;   // reference levels of wide-block trees with at least that many blocks: k_factor_lchain + k_factor_ref_finish
+  int lchain_ref_on = 1, lchain_ref_min = 1;   // reference levels of wide-block trees (with at least that many blocks): k_factor_lchain + k_factor_ref_finish
   int leaf_wide = 1;                          // k_sample_leaf_wide for the non-reference levels of wide-block trees (SPAMTREE_LEAF_WIDE=0: the generic kernel)
   int leaf_seg = 1;                           // k_sample_leaf_seg (segment-aligned lanes) where eligible
   int gram_direct_level = -1;                 // >= 0: that (last reference) level forms its children's Gram parts itself: k_gram_direct
@@ -556,7 +556,7 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
     { const char *e = getenv("SPAMTREE_WIDE"); h->wide_on = (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1); }
     { const char *e = getenv("SPAMTREE_LCHAIN"); h->lchain_on = (e && e[0] == '0') ? 0 : 1; }
     { const char *e = getenv("SPAMTREE_LCHAIN_REF"); h->lchain_ref_on = (e && e[0] == '0') ? 0 : 1; }
-    { const char *e = getenv("SPAMTREE_LCHAIN_REF_MIN"); h->lchain_ref_min = e ? atoi(e) : 256; }
+    { const char *e = getenv("SPAMTREE_LCHAIN_REF_MIN"); h->lchain_ref_min = e ? atoi(e) : 1; }
     { const char *e = getenv("SPAMTREE_GRAM_BIG"); h->gram_big = (e && e[0] == '0') ? 0 : 1; }
   }
   h->levels.resize(n_actual);
@@ -687,8 +687,9 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
           for (int b : list) all_anc = all_anc && h->blks[b].nanc >= 1 && !h->blks[b].isref;
           if (all_anc) L.lchain = L.maxP <= 384 ? 96 : 136;
         }
-        // REFERENCE levels of many blocks (round 3): k_factor_lchain for the chain pass (it runs it at more than twice
-        // k_factor_bigmfma's rate), then k_factor_ref_finish per block.  L.count, not the rank's share: a property of the level
+        // REFERENCE levels behind a chain (round 3): k_factor_lchain for the chain pass (it runs it at more than twice
+        // k_factor_bigmfma's rate, and a block's columns are two slabs on two CUs: the single-block top levels gain too), then
+        // k_factor_ref_finish per block.  L.count, not the rank's share: a property of the level
         if (L.bigmfma && h->lchain_on && h->lchain_ref_on && !h->limited && L.isref && L.maxM <= 80 && L.maxP <= 544 && L.count >= h->lchain_ref_min) {
           bool all_anc = true;
           for (int b : list) all_anc = all_anc && h->blks[b].nanc >= 1 && h->blks[b].isref;

@@ -104,7 +104,7 @@ def gpu_worker(rank, world, port, side, q, out_dir, steps, limited=False):
     xty, ssq = m.stats()
     info = m.shard_info() if world > 1 else {}
     kernels = np.array([{"generic_lds": 0, "generic_scratch": 1, "k_factor_mfma": 2, "k_factor_quad": 3, "k_factor_bigmfma": 4,
-                         "k_factor_wide": 5, "k_factor_lchain": 6}[L["kernel"]] for L in m.level_info()])
+                         "k_factor_wide": 5, "k_factor_lchain": 6, "k_factor_lchain+ref_finish": 7}[L["kernel"]] for L in m.level_info()])
     np.savez(os.path.join(out_dir, f"res_{world}_{rank}.npz"), w=m.get_w(), xty=xty, ssq=ssq,
              owned_rows=info.get("owned_rows", wl["n"]), kernels=kernels, **res)
     m.close()

@@ -56,6 +56,7 @@ def test_config4_chains_bigmfma_second_pass(nx, leaf_inst, wide, lchain, monkeyp
     block per workgroup, second pass beyond 384 rows."""
     monkeypatch.setenv("SPAMTREE_WIDE", wide)
     monkeypatch.setenv("SPAMTREE_LCHAIN", lchain)   # "1" (the default): the leaf level on k_factor_lchain
+    monkeypatch.setenv("SPAMTREE_LCHAIN_REF", "0")  # the reference levels stay on the older kernels here (the default route: the test below)
     coords, mv = strip_coords(nx, 10, 3)
     pb = make_problem(coords=coords, mv_id=mv, q=3, seed=3, K=(2, 1), tree_depth=7)
 
@@ -87,9 +88,8 @@ def test_config5_chains_201_to_256_on_k_factor_mfma():
 @pytest.mark.parametrize("nx", [370, 400])
 def test_config4_reference_levels_on_lchain_and_ref_finish(nx, monkeypatch):
     """Reference levels of a wide-block tree as k_factor_lchain (chain pass, columns treated as conditionally independent)
-    + k_factor_ref_finish (Schur complement, blocked factorisation, -Ri T in place): by default only levels of >= 256 blocks
-    take this route (config #4's levels 5-6); SPAMTREE_LCHAIN_REF_MIN=1 puts every reference level behind a chain on it."""
-    monkeypatch.setenv("SPAMTREE_LCHAIN_REF_MIN", "1")
+    + k_factor_ref_finish (Schur complement from the V scratch, blocked factorisation, -Ri T in place): the default route of
+    every reference level behind a chain (SPAMTREE_LCHAIN_REF=0 / SPAMTREE_LCHAIN_REF_MIN: off / only levels of that many blocks)."""
     coords, mv = strip_coords(nx, 10, 3)
     pb = make_problem(coords=coords, mv_id=mv, q=3, seed=3, K=(2, 1), tree_depth=7)
 

@@ -369,9 +369,12 @@ def test_factor_kernel_generations(case, gen, monkeypatch):
     hm.close()
 
 
-def test_big_block_kernel_two_passes():
-    """k_factor_bigmfma on the default multivariate tree (q = 3: 75-row blocks) deep enough for chains of 294 rows, i.e.
-    both passes over the chain (chain tiles 0-16 and 17-..): factors against the oracle and against the generic kernels."""
+@pytest.mark.parametrize("ref_route", ["0", "1"])
+def test_big_block_kernel_two_passes(ref_route, monkeypatch):
+    """The default multivariate tree (q = 3: 75-row blocks) deep enough for chains of 294 rows: factors against the oracle and
+    against the generic kernels.  ref_route = "0": k_factor_bigmfma, both passes over the chain (chain tiles 0-16 and 17-..);
+    "1" (the default): reference levels on k_factor_lchain + k_factor_ref_finish."""
+    monkeypatch.setenv("SPAMTREE_LCHAIN_REF", ref_route)
     pb = make_problem(side=50, q=3, seed=3)
     rng = np.random.default_rng(2)
     w0 = rng.standard_normal(pb["n"])

@@ -43,7 +43,7 @@ def test_sharded_equals_single_process_bitwise(side, q, quad_min, env, tmp_path,
         mp.spawn(gpu_worker, args=(world, free_port(), side, q, str(tmp_path), steps), nprocs=world, join=True)
     ref = np.load(tmp_path / "res_1_0.npz")
     if expect_lchain:
-        assert 6 in ref["kernels"].tolist(), ref["kernels"]      # ST_KERNEL_LCHAIN: the case reaches the kernel it is meant to cover
+        assert 6 in ref["kernels"].tolist() and 7 in ref["kernels"].tolist(), ref["kernels"]      # ST_KERNEL_LCHAIN / _LCHAIN_REF: the case reaches the kernels it is meant to cover
     for world in (2, 3, 4):
         rows = 0
         for rank in range(world):
