@@ -81,8 +81,9 @@ __host__ __device__ constexpr size_t rf_work_doubles(int maxM) {
   const size_t a = (size_t)2 * maxM * maxM, b = (size_t)RF_NBUF * RF_BUFD;
   return a > b ? a : b;
 }
-__host__ __device__ constexpr size_t rf_lds_bytes(int maxM) {   // w, x, y, T w_pa, 1 / r of the block | work | outcome ids
-  return (5 * (size_t)maxM + rf_work_doubles(maxM)) * 8 + (size_t)((maxM + 1) & ~1) * 4 + 64;
+#define RF_NOPS 60     // A operands of N = -Ri T: (row tile it, K-step s2 < 4 (it + 1)), it < 5, at 2 it (it + 1) + s2
+__host__ __device__ constexpr size_t rf_lds_bytes(int maxM) {   // w, x, y, T w_pa, 1 / r of the block | work | -Ri in operand order | outcome ids
+  return (5 * (size_t)maxM + rf_work_doubles(maxM) + RF_NOPS * 64) * 8 + (size_t)((maxM + 1) & ~1) * 4 + 64;
 }
 __host__ __device__ constexpr long long rf_vsize(int P) { return (long long)((P + 3) & ~3) * RF_LDB; }   // a block's V in the scratch (doubles)
 
@@ -596,7 +597,8 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
   double *work = rinv + maxM;   // the Schur product's staging buffers, then R | Ri
   double *Rl = work;
   double *Ril = Rl + (size_t)maxM * maxM;
-  int *smv = (int *)(work + rf_work_doubles(maxM));
+  double *nri = work + rf_work_doubles(maxM);   // RF_NOPS x 64: -Ri as the MFMA A operands of the N phase (zero above the diagonal / beyond the block)
+  int *smv = (int *)(nri + RF_NOPS * 64);
   lc_cov_table(s_cpt, cp, tid, BM_NT);
   const int qn = cp.q;
   const double s2 = cp.ai1[0], nphi = -cp.tmv[0];
@@ -707,6 +709,15 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
     {
       const int nkt = (P + 15) >> 4;
       double *dump = const_cast<double *>(Vb) + tid;
+      // -Ri in operand order, once per block: an A operand of the loop below is ONE LDS read at an immediate offset (built per MFMA --
+      // clamped address, two compares, select, negation -- it cost about ten VALU instructions on the pipe the FP64 MFMAs use)
+      for (int idx = tid; idx < RF_NOPS * 64; idx += BM_NT) {
+        const int o = idx >> 6, ln = idx & 63;
+        const int it = o >= 40 ? 4 : (o >= 24 ? 3 : (o >= 12 ? 2 : (o >= 4 ? 1 : 0)));
+        const int s2 = o - 2 * it * (it + 1), ia = it * 16 + (ln & 15), j = 4 * s2 + (ln >> 4);
+        nri[idx] = (ia < m && j <= ia) ? -Ril[ia * m + j] : 0.0;
+      }
+      __syncthreads();
       auto apply = [&](auto fullc) {
         constexpr bool FULL = decltype(fullc)::value;
         double tn[20];   // B operands of the wave's NEXT column block: T[j = 4 s + l4][kb], raw panel entries
@@ -730,17 +741,12 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
 #pragma unroll
           for (int it = 0; it < 5; ++it) {
             if (FULL || it < JT) {
-              const int ia = it * 16 + l15;
               d4 c = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
               for (int s2 = 0; s2 < 20; ++s2) {
-                if (4 * s2 < it * 16 + 16) {   // (compile time) Ri is lower triangular: row tile `it` needs columns < 16 (it + 1); rows of
-                                               // T beyond the block are zero operands: no run-time guard, a tile's MFMAs are one basic block
-                  const int j = 4 * s2 + l4;
-                  const double a0 = Ril[min(ia, m - 1) * m + min(j, m - 1)];
-                  const double a1 = (ia < m && j <= ia) ? -a0 : 0.0;
-                  c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, tb[s2], c, 0, 0, 0);
-                }
+                if (4 * s2 < it * 16 + 16)   // (compile time) Ri is lower triangular: row tile `it` needs columns < 16 (it + 1); rows of
+                                             // T beyond the block are zero operands: no run-time guard, a tile's MFMAs are one basic block
+                  c = __builtin_amdgcn_mfma_f64_16x16x4f64(nri[(2 * it * (it + 1) + s2) * 64 + lane], tb[s2], c, 0, 0, 0);
               }
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
