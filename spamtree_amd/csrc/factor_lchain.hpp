@@ -708,7 +708,7 @@ __global__ __launch_bounds__(BM_NT) void k_factor_ref_finish(FactorArgs A, CovPa
     // has consumed), and the last round requests its own block once more (the first round's wait is the loop's peeled prologue).
     {
       const int nkt = (P + 15) >> 4;
-      double *dump = const_cast<double *>(Vb) + tid;
+      double *dump = const_cast<double *>(Vb) + lane;   // (inside the block's own V for any P: it holds at least 4 x 80 doubles)
       // -Ri in operand order, once per block: an A operand of the loop below is ONE LDS read at an immediate offset (built per MFMA --
       // clamped address, two compares, select, negation -- it cost about ten VALU instructions on the pipe the FP64 MFMAs use)
       for (int idx = tid; idx < RF_NOPS * 64; idx += BM_NT) {

@@ -214,19 +214,29 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       N = Np;
     }
     __syncthreads();
-    for (int i0 = 4 * wid; i0 < m; i0 += 4 * (NT / 64)) {   // four rows per trip: their loads travel together
-      double a4[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int k = lane; k < P; k += 64) {
-        const double wk = wv[k];
+    // Segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j] (ancestor t's part of row r of N w_pa), ONE coalesced pass over the
+    // chain part of the panel: a 32-lane half-wave per (row, ancestor), its lanes on consecutive entries, a fixed-order butterfly.
+    // N w_pa is their sum over the ancestors, and the messages below take ev - seg from here -- round 2 walked the panel once for
+    // N w_pa (a wave per four rows) and once more for the segments (a THREAD per (row, ancestor): 64 rows per load instruction).
+    {
+      const int half = lane >> 5, l32 = lane & 31, ntask = m * J;
+      for (int base = 2 * wid; base < ntask; base += 2 * (NT / 64)) {
+        const int task = min(base + half, ntask - 1), r = task / J, t = task - r * J;
+        const int ma = s_am[t], oa = s_ao[t];
+        const double *row = N + (size_t)r * ld + oa;
+        const double *wa = wv + oa;
+        double a = 0.0;
+        for (int j = l32; j < ma; j += 32) a += row[j] * wa[j];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (i0 + q < m) a4[q] += N[(size_t)(i0 + q) * ld + k] * wk;
+        for (int o = 16; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (l32 == 0 && base + half < ntask) seg[t * maxM + r] = a;
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const double r = wave_sum(a4[q]);
-        if (lane == 0 && i0 + q < m) tv[i0 + q] = r;
-      }
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) {
+      double a = 0.0;
+      for (int t = 0; t < J; ++t) a += seg[t * maxM + i];
+      tv[i] = a;
     }
     __syncthreads();
 
@@ -340,18 +350,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       // sums its segment N[r][oa_t ..] w_a, then thread k (a chain column) accumulates -sum_r N[r][k] (ev[r] - seg_t(k)[r])
       for (int idx = tid; idx < m * J; idx += NT) {
         const int r = idx / J, t = idx - r * J;
-        const int ma = s_am[t], oa = s_ao[t];
-        const double *row = N + (size_t)r * ld + oa;
-        const double *wa = wv + oa;
-        double a = 0.0;
-        for (int j0 = 0; j0 < ma; j0 += 8) {
-          double x[8];
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) x[jj] = (j0 + jj < ma) ? row[j0 + jj] : 0.0;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) a += x[jj] * ((j0 + jj < ma) ? wa[j0 + jj] : 0.0);
-        }
-        seg[t * maxM + r] = ev[r] - a;
+        seg[t * maxM + r] = ev[r] - seg[t * maxM + r];
       }
       __syncthreads();
       STAMP(4);
@@ -382,11 +381,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     long long off = 0;
     for (int t = 0; t < J; ++t) {
       const int ma = s_am[t], oa = s_ao[t];
-      for (int r = tid; r < m; r += NT) {
-        double acc = ev[r];
-        for (int j = 0; j < ma; ++j) acc -= N[(size_t)r * ld + oa + j] * wv[oa + j];
-        av[r] = acc;
-      }
+      for (int r = tid; r < m; r += NT) av[r] = ev[r] - seg[t * maxM + r];
       __syncthreads();
       double *out = A.acc + B.acc_off + off;
       for (int idx = A.do_gram ? tid : ma * ma + tid; idx < ma * ma + ma; idx += NT) {
