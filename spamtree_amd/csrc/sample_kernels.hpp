@@ -220,16 +220,36 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     // N w_pa (a wave per four rows) and once more for the segments (a THREAD per (row, ancestor): 64 rows per load instruction).
     {
       const int half = lane >> 5, l32 = lane & 31, ntask = m * J;
-      for (int base = 2 * wid; base < ntask; base += 2 * (NT / 64)) {
-        const int task = min(base + half, ntask - 1), r = task / J, t = task - r * J;
-        const int ma = s_am[t], oa = s_ao[t];
-        const double *row = N + (size_t)r * ld + oa;
-        const double *wa = wv + oa;
-        double a = 0.0;
-        for (int j = l32; j < ma; j += 32) a += row[j] * wa[j];
+      for (int base = 8 * wid; base < ntask; base += 8 * (NT / 64)) {   // four (row, ancestor) pairs per half-wave and trip: their
+        double a[4];                                                     // loads (up to three each) travel together
+        const double *row[4], *wa[4];
+        int ma[4];
 #pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) a += __shfl_xor(a, o, 64);
-        if (l32 == 0 && base + half < ntask) seg[t * maxM + r] = a;
+        for (int u = 0; u < 4; ++u) {
+          const int task = min(base + 2 * u + half, ntask - 1), r = task / J, t = task - r * J;
+          ma[u] = s_am[t];
+          row[u] = N + (size_t)r * ld + s_ao[t];
+          wa[u] = wv + s_ao[t];
+        }
+        double x[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) x[u][c] = (l32 + 32 * c < ma[u]) ? row[u][l32 + 32 * c] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a[u] = 0.0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a[u] += x[u][c] * ((l32 + 32 * c < ma[u]) ? wa[u][l32 + 32 * c] : 0.0);
+          for (int j = l32 + 96; j < ma[u]; j += 32) a[u] += row[u][j] * wa[u][j];   // (ancestors wider than 96 rows)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+          for (int o = 16; o >= 1; o >>= 1) a[u] += __shfl_xor(a[u], o, 64);
+          const int task = base + 2 * u + half;
+          if (l32 == 0 && task < ntask) { const int r = task / J, t = task - r * J; seg[t * maxM + r] = a[u]; }
+        }
       }
     }
     __syncthreads();
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
       const int ms = (BIG && A.lds_sq) ? ((m + 7) | 1) : m;   // row stride of S
       const long long so = (BIG && A.s0off) ? A.s0off[b] : -1;
-#pragma unroll 4
+#pragma unroll 8
       for (int idx = tid; idx < m * m; idx += NT) {
         const int i = idx / m, j = idx - i * m;
         if (j <= i) {
@@ -267,17 +287,26 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         }
       }
       // Smu_tot = A_u' w_pa + sum_children Smu_children + tausq_inv*(y - XB)   (:1062-1077)
-      for (int i = tid; i < m; i += NT) {
+      // - Ri' (N w_pa), walking Ri by ROWS (thread i reads entry i of row k: coalesced).  Blocks of up to NT / 2 rows: two threads
+      // per row (rows k of equal parity from the diagonal), sixteen entries in flight each, the two halves added in a fixed order
+      // through `av` (a latency chain of ten batches of eight before)
+      const int np = 2 * m <= NT ? 2 : 1;
+      for (int it = tid; it < np * m; it += NT) {
+        const int i = it % m, part = it / m;
         double acc = 0.0;
-        // - Ri' (N w_pa), walking Ri by ROWS (thread i reads entry i of row k: coalesced; same summation order as the column walk)
-        for (int k0 = 0; k0 < m; k0 += 8) {
-          double x[8];
+        for (int k0 = i + part; k0 < m; k0 += 16 * np) {
+          double x[16];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) x[q] = (k0 + q < m && k0 + q >= i) ? Ri[(size_t)(k0 + q) * ld + i] : 0.0;
+          for (int q = 0; q < 16; ++q) x[q] = Ri[(size_t)min(k0 + q * np, m - 1) * ld + i];
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (k0 + q < m && k0 + q >= i) acc -= x[q] * tv[k0 + q];
+          for (int q = 0; q < 16; ++q)
+            if (k0 + q * np < m) acc -= x[q] * tv[k0 + q * np];
         }
+        if (part == 1) av[i] = acc; else bv[i] = acc;
+      }
+      __syncthreads();
+      for (int i = tid; i < m; i += NT) {
+        double acc = bv[i] + (np == 2 ? av[i] : 0.0);
         for (int c = 0; c < B.ndch; ++c) {
           const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
           acc += A.acc[co + B.acc_len + m * m + i];
@@ -321,10 +350,19 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         A.w[B.row0 + i] = bv[i];
       }
       __syncthreads();
-      for (int i = tid; i < m; i += NT) {
-        double acc = tv[i];
-        for (int j = 0; j <= i; ++j) acc += Ri[(size_t)i * ld + j] * wv[P + j];
-        ev[i] = acc;
+      for (int i0 = 4 * wid; i0 < m; i0 += 4 * (NT / 64)) {   // ev = Ri w_u + N w_pa: a wave per row (coalesced), four rows per trip
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = lane; j < m; j += 64) {
+          const double wj = wv[P + j];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (i0 + q < m && j <= i0 + q) a4[q] += Ri[(size_t)(i0 + q) * ld + j] * wj;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double r = wave_sum(a4[q]);
+          if (lane == 0 && i0 + q < m) ev[i0 + q] = tv[i0 + q] + r;
+        }
       }
     } else {
       // non-reference rows (:1091-1155)
@@ -361,16 +399,17 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         const int ma = s_am[t], i = k - s_ao[t];
         const double *avt = seg + t * maxM;
         double a = 0.0;
-        for (int r0 = 0; r0 < m; r0 += 8) {
-          double x[8];
+        for (int r0 = 0; r0 < m; r0 += 16) {
+          double x[16];
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) x[rr] = (r0 + rr < m) ? N[(size_t)(r0 + rr) * ld + k] : 0.0;
+          for (int rr = 0; rr < 16; ++rr) x[rr] = N[(size_t)min(r0 + rr, m - 1) * ld + k];
 #pragma unroll
-          for (int rr = 0; rr < 8; ++rr) a -= x[rr] * ((r0 + rr < m) ? avt[r0 + rr] : 0.0);
+          for (int rr = 0; rr < 16; ++rr)
+            if (r0 + rr < m) a -= x[rr] * avt[r0 + rr];
         }
         for (int c = 0; c < (A.no_fwd ? 0 : B.ndch); ++c) {
-          const Blk C = A.blks[A.dch_idx[B.dch_ptr + c]];
-          a += A.acc[C.acc_off + s_aoff[t] + ma * ma + i];
+          const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;   // (read once per block above)
+          a += A.acc[co + s_aoff[t] + ma * ma + i];
         }
         rec[s_aoff[t] + ma * ma + i] = a;
       }
