@@ -220,31 +220,32 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
     // N w_pa (a wave per four rows) and once more for the segments (a THREAD per (row, ancestor): 64 rows per load instruction).
     {
       const int half = lane >> 5, l32 = lane & 31, ntask = m * J;
-      for (int base = 8 * wid; base < ntask; base += 8 * (NT / 64)) {   // four (row, ancestor) pairs per half-wave and trip: their
-        double a[4];                                                     // loads (up to three each) travel together
-        const double *row[4], *wa[4];
-        int ma[4];
+      constexpr int SU = 4;   // (row, ancestor) pairs per half-wave and trip: their loads (up to three each) travel together
+      for (int base = 2 * SU * wid; base < ntask; base += 2 * SU * (NT / 64)) {
+        double a[SU];
+        const double *row[SU], *wa[SU];
+        int ma[SU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SU; ++u) {
           const int task = min(base + 2 * u + half, ntask - 1), r = task / J, t = task - r * J;
           ma[u] = s_am[t];
           row[u] = N + (size_t)r * ld + s_ao[t];
           wa[u] = wv + s_ao[t];
         }
-        double x[4][3];
+        double x[SU][3];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < SU; ++u)
 #pragma unroll
           for (int c = 0; c < 3; ++c) x[u][c] = (l32 + 32 * c < ma[u]) ? row[u][l32 + 32 * c] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SU; ++u) {
           a[u] = 0.0;
 #pragma unroll
           for (int c = 0; c < 3; ++c) a[u] += x[u][c] * ((l32 + 32 * c < ma[u]) ? wa[u][l32 + 32 * c] : 0.0);
           for (int j = l32 + 96; j < ma[u]; j += 32) a[u] += row[u][j] * wa[u][j];   // (ancestors wider than 96 rows)
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < SU; ++u) {
 #pragma unroll
           for (int o = 16; o >= 1; o >>= 1) a[u] += __shfl_xor(a[u], o, 64);
           const int task = base + 2 * u + half;
@@ -266,24 +267,57 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
       // Sigi_tot = Ri'Ri + sum_children Sigi_children + diag(tausq_inv)      (:1044-1051)
       const int ms = (BIG && A.lds_sq) ? ((m + 7) | 1) : m;   // row stride of S
       const long long so = (BIG && A.s0off) ? A.s0off[b] : -1;
-#pragma unroll 8
-      for (int idx = tid; idx < m * m; idx += NT) {
-        const int i = idx / m, j = idx - i * m;
-        if (j <= i) {
-          double acc = 0.0;
-          if (so >= 0 && !A.do_gram) acc = A.s0[so + idx];   // Ri' Ri is a function of theta only
-          else {
-            for (int k = i; k < m; ++k) acc += Ri[(size_t)k * ld + i] * Ri[(size_t)k * ld + j];
-            if (so >= 0) A.s0[so + idx] = acc;
+      // The lower triangle only, entry e = i (i + 1) / 2 + j, six entries per thread and trip with every load of the trip in flight
+      // (s0 or -- first sweep after an accepted theta on this path -- Ri' Ri formed here, the children's parts); the upper
+      // triangle is zero, the diagonal's tausq_inv comes from `ev` (filled below, free until the draw).  Round 2 walked the full
+      // square behind an `if (j <= i)`: no two entries' loads travelled together (22 dependent round trips per thread at m = 75).
+      double *Sl = (BIG && A.lds_sq) ? Np : S;
+      for (int idx = tid; idx < m * ms; idx += NT) Sl[idx] = 0.0;
+      for (int i = tid; i < m; i += NT) ev[i] = A.tausq_inv[A.mv[B.row0 + i]];
+      __syncthreads();
+      {
+        const int ntri = m * (m + 1) / 2;
+        const bool cached = so >= 0 && !A.do_gram;
+        const int nch = min(B.ndch, 16);
+        for (int e0 = tid; e0 < ntri; e0 += 6 * NT) {
+          double acc[6];
+          int ii[6], jj[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int e = min(e0 + u * NT, ntri - 1);
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while (i * (i + 1) / 2 > e) --i;
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            ii[u] = i; jj[u] = e - i * (i + 1) / 2;
           }
-          for (int c = 0; c < B.ndch; ++c) {
-            const long long co = c < 16 ? s_choff[c] : A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
-            acc += A.acc[co + B.acc_len + idx];
+          if (cached) {   // Ri' Ri is a function of theta only
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc[u] = A.s0[so + ii[u] * m + jj[u]];
+          } else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+              double a = 0.0;
+              for (int k = ii[u]; k < m; ++k) a += Ri[(size_t)k * ld + ii[u]] * Ri[(size_t)k * ld + jj[u]];
+              if (so >= 0 && e0 + u * NT < ntri) A.s0[so + ii[u] * m + jj[u]] = a;
+              acc[u] = a;
+            }
           }
-          if (i == j) acc += A.tausq_inv[A.mv[B.row0 + i]];
-          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = acc; else S[(size_t)i * ms + j] = acc;
-        } else {
-          if (BIG && A.lds_sq) Np[(size_t)i * ms + j] = 0.0; else S[(size_t)i * ms + j] = 0.0;
+          for (int c = 0; c < nch; ++c) {
+            const double *rc = A.acc + s_choff[c] + B.acc_len;
+            double x[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) x[u] = rc[ii[u] * m + jj[u]];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc[u] += x[u];
+          }
+          for (int c = 16; c < B.ndch; ++c) {
+            const long long co = A.blks[A.dch_idx[B.dch_ptr + c]].acc_off;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) acc[u] += A.acc[co + B.acc_len + ii[u] * m + jj[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < 6; ++u)
+            if (e0 + u * NT < ntri) Sl[(size_t)ii[u] * ms + jj[u]] = acc[u] + (ii[u] == jj[u] ? ev[ii[u]] : 0.0);
         }
       }
       // Smu_tot = A_u' w_pa + sum_children Smu_children + tausq_inv*(y - XB)   (:1062-1077)
@@ -312,7 +346,7 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
           acc += A.acc[co + B.acc_len + m * m + i];
         }
         const long long r = B.row0 + i;
-        acc += A.tausq_inv[A.mv[r]] * (A.y[r] - A.xb[r]);
+        acc += ev[i] * (A.y[r] - A.xb[r]);
         bv[i] = acc;
       }
       if (BIG && A.lds_sq) {
@@ -350,17 +384,28 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
         A.w[B.row0 + i] = bv[i];
       }
       __syncthreads();
-      for (int i0 = 4 * wid; i0 < m; i0 += 4 * (NT / 64)) {   // ev = Ri w_u + N w_pa: a wave per row (coalesced), four rows per trip
-        double a4[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int j = lane; j < m; j += 64) {
-          const double wj = wv[P + j];
+      for (int i0 = 8 * wid; i0 < m; i0 += 8 * (NT / 64)) {   // ev = Ri w_u + N w_pa: a wave per row (coalesced), eight rows per trip
+        double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int j0 = 0; j0 < m; j0 += 128) {
+          double x[8][2];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (i0 + q < m && j <= i0 + q) a4[q] += Ri[(size_t)(i0 + q) * ld + j] * wj;
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int j = j0 + lane + 64 * c;
+              x[q][c] = (i0 + q < m && j <= i0 + q) ? Ri[(size_t)(i0 + q) * ld + j] : 0.0;
+            }
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int j = j0 + lane + 64 * c;
+            const double wj = j < m ? wv[P + j] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a8[q] += x[q][c] * wj;
+          }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double r = wave_sum(a4[q]);
+        for (int q = 0; q < 8; ++q) {
+          const double r = wave_sum(a8[q]);
           if (lane == 0 && i0 + q < m) ev[i0 + q] = tv[i0 + q] + r;
         }
       }
