@@ -1330,12 +1330,68 @@ __global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
     for (int j = 1; j < J; ++j) t += k >= ao_of(j) ? 1 : 0;   // independent compares, not a search loop of dependent LDS reads
     wv[k] = A.w[s_gd[8 + 4 * t + 1] + (k - ao_of(t))];
   }
+  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j].
+  // Round 3: the chain part of the panel is read by ROWS (lanes on consecutive entries: whole 512-byte runs), four rows per trip
+  // through an LDS staging area, and lane (row, ancestor) then walks its segment there -- in the order and with the arithmetic of
+  // the direct form below, whose 64 lanes read 64 different 25-entry segments per load instruction (63 sectors per request
+  // instead of 8: the kernel was bound by those requests).  The staging area is Ri's (filled afterwards from registers
+  // requested up front); blocks too short for it to hold a chain row keep the direct form.
+  const int PS = P | 1;
+  const int RG = min(4, (A.Mrows * CH_LD) / PS);
+  if (RG >= 1) {   // wave-uniform
+    constexpr int NRI = (27 * 27 + 63) / 64;
+    double rireg[NRI];
+#pragma unroll
+    for (int q = 0; q < NRI; ++q) {
+      const int idx = lane + 64 * q, i = idx / M, j = idx - i * M;
+      rireg[q] = (idx < M * M && j <= i) ? A.panels[bpan + (size_t)i * bld + P + j] : 0.0;
+    }
+    double *stg = Rc;
+    for (int r0 = 0; r0 < M; r0 += RG) {
+      for (int c0 = 0; 64 * c0 < P; c0 += 4) {
+        double x[4][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = lane + 64 * (c0 + c);
+            x[rr][c] = (rr < RG && r0 + rr < M && k < P) ? A.panels[bpan + (size_t)(r0 + rr) * bld + k] : 0.0;
+          }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int k = lane + 64 * (c0 + c);
+            if (rr < RG && k < P) stg[rr * PS + k] = x[rr][c];
+          }
+      }
+      WSYNC();
+      if (lane < RG * J) {
+        const int rr = lane / J, t = lane - rr * J, r = r0 + rr;
+        if (r < M) {
+          const int ma = am_of(t), oa = ao_of(t);
+          const double *srow = stg + rr * PS + oa;
+          const double *wa = wv + oa;
+          double a = 0.0;
+          for (int j = 0; j < ma; ++j) a += srow[j] * wa[j];
+          seg[t * 32 + r] = a;
+        }
+      }
+      // (the next trip's stores follow these reads in program order: one wave's LDS operations execute in order)
+    }
+    WSYNC();
+#pragma unroll
+    for (int q = 0; q < NRI; ++q) {   // Ri -> LDS (the panel's last M columns)
+      const int idx = lane + 64 * q, i = idx / M, j = idx - i * M;
+      if (idx < M * M) Rc[i * CH_LD + j] = rireg[q];
+    }
+    WSYNC();
+  } else {
   for (int idx = lane; idx < M * M; idx += 64) {     // Ri -> LDS (the panel's last M columns)
     const int i = idx / M, j = idx - i * M;
     Rc[i * CH_LD + j] = (j <= i) ? A.panels[bpan + (size_t)i * bld + P + j] : 0.0;
   }
   WSYNC();
-  // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
   for (int idx = lane; idx < M * J; idx += 64) {
     const int r = idx / J, t = idx - r * J;
     const int ma = am_of(t), oa = ao_of(t);
@@ -1352,6 +1408,7 @@ __global__ __launch_bounds__(NT, 3) void k_sample_wave(SampleFastArgs A) {
     seg[t * 32 + r] = a;
   }
   WSYNC();
+  }
   double tvi = 0.0;
   if (row) { for (int t = 0; t < J; ++t) tvi += seg[t * 32 + lane]; tv[lane] = tvi; }
   WSYNC();
