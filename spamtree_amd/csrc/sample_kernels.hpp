@@ -1658,21 +1658,27 @@ __global__ __launch_bounds__(NT, NCH <= 4 ? 4 : 3) void k_sample_leaf_seg(Sample
   const Grp G = {B0.row0, B0.blk0, B0.nblk, B0.M, B0.P};
   const int M = G.M, P = G.P, J = B0.nanc;
   if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
+  // The rows' own data (tid 32..63: outcome id -> tausq_inv is a dependent pair of loads) travels WITH the ancestors' w and the first
+  // batch of panel rows instead of ahead of them: requested here, parked in registers over an LDS-only barrier, stored after the
+  // other requests have been issued (a group is a chain of dependent round trips -- 7 rows per wave's worth of arithmetic --, so
+  // each one taken off the chain counts: round 3, leaf sweep 0.28 ms at n = 1e6)
+  double t_ = 0.0, y_ = 0.0, z_ = 0.0, xb_ = 0.0;
+  int mv_ = 0;
+  const bool rowthr = tid >= 32 && tid < 64 && tid - 32 < M;
   if (tid >= 32 && tid < 64) {
     const int j = tid - 32;
-    double t_ = 0.0, y_ = 0.0, z_ = 0.0;
     long long ro = 0;
     if (j < M) {
       const long long r = G.row0 + j;
-      t_ = A.tausq_inv[A.mv[r]]; y_ = A.y[r] - A.xb[r]; z_ = A.z[r];
+      mv_ = A.mv[r]; y_ = A.y[r]; xb_ = A.xb[r]; z_ = A.z[r];
       int bi = 0;
       const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
       while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
       ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
     }
-    tsq[j] = t_; yx[j] = y_; zc[j] = z_; s_rowoff[j] = ro;
+    s_rowoff[j] = ro;
   }
-  __syncthreads();
+  lds_barrier();   // (LDS only: the loads above stay in flight)
   // this lane's columns: chunk c -> ancestor t = 2 c + (lane >> 5), its row i = lane & 31
   const int hi = lane >> 5, li = lane & 31;
   int kc[NCH];       // chain column, or -1
@@ -1685,9 +1691,8 @@ __global__ __launch_bounds__(NT, NCH <= 4 ? 4 : 3) void k_sample_leaf_seg(Sample
     wk[c] = ok ? A.w[s_arow[t] + li] : 0.0;
     acc[c] = 0.0;
   }
-#pragma unroll 1
-  for (int b = 0; b < 2; ++b) {
-    double v[4][NCH], rjv[4];
+  double v[4][NCH], rjv[4];   // a batch of panel rows: rows wid + 4 (4 b + rr)
+  auto fetch = [&](int b) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int j = wid + 4 * (4 * b + rr);
@@ -1695,6 +1700,17 @@ __global__ __launch_bounds__(NT, NCH <= 4 ? 4 : 3) void k_sample_leaf_seg(Sample
 #pragma unroll
       for (int c = 0; c < NCH; ++c) v[rr][c] = (j < M && kc[c] >= 0) ? src[kc[c]] : 0.0;
       rjv[rr] = j < M ? src[P] : 0.0;          // the row's r_j (same address for every lane)
+    }
+  };
+  fetch(0);
+  if (rowthr) t_ = A.tausq_inv[mv_];
+  if (tid >= 32 && tid < 64) { const int j = tid - 32; tsq[j] = t_; yx[j] = y_ - xb_; zc[j] = z_; }
+  __syncthreads();
+#pragma unroll 1
+  for (int b = 0; b < 2; ++b) {
+    if (b == 1) {
+      if (M <= 16) break;   // (workgroup-uniform) no second batch
+      fetch(1);
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
