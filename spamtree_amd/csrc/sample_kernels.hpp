@@ -39,6 +39,8 @@ struct GramBigArgs {
   double *s0;
   const long long *s0off;
   int no_fwd;
+  int mirror;     // 1: off-diagonal tiles are written to both triangles (a reader on another kernel family takes full squares); 0: the
+                  // reader is k_gram_big / the generic sweep's cached branch, which take tiles it >= jt / the lower triangle only
 };
 
 // the column-group kernels: k_sample_mfma, k_gram, k_gram_direct, k_sample_lean, k_sample_wave, k_sample_leaf, k_sample_leaf_seg
@@ -501,9 +503,10 @@ __global__ __launch_bounds__(NT) void k_sample(SampleArgs A) {
 // from global memory / L2 (16 consecutive doubles per row: whole 128-byte segments).  Fixed summation order.
 
 __global__ __launch_bounds__(NT) void k_gram_big(GramBigArgs A) {
-  __shared__ int s_am[MAXJ + 1], s_ao[MAXJ + 1], s_t0[MAXJ + 2];
+  __shared__ int s_am[MAXJ + 1], s_ao[MAXJ + 1];
   __shared__ long long s_aoff[MAXJ + 1];
   __shared__ long long s_choff[16];
+  __shared__ double s_tr[NT / 64][16 * 17];   // per wave: a tile on its way to the mirrored position
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = A.list[blockIdx.x];
@@ -514,65 +517,96 @@ __global__ __launch_bounds__(NT) void k_gram_big(GramBigArgs A) {
   if (tid >= 64 && tid < 64 + min(B.ndch, 16)) s_choff[tid - 64] = A.blks[A.dch_idx[B.dch_ptr + tid - 64]].acc_off;
   __syncthreads();
   if (tid == 0) {
-    int o = 0, tasks = 0;
+    int o = 0;
     long long ao = 0;
-    for (int t = 0; t < J; ++t) {
-      const int nt = (s_am[t] + 15) >> 4;
-      s_ao[t] = o; s_aoff[t] = ao; s_t0[t] = tasks;
-      o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; tasks += nt * (nt + 1) / 2;
-    }
-    s_t0[J] = tasks;
-    if (so >= 0) { s_am[J] = m; s_ao[J] = P; s_aoff[J] = 0; const int nt = (m + 15) >> 4; tasks += nt * (nt + 1) / 2; }
-    s_t0[J + 1] = tasks;
+    for (int t = 0; t < J; ++t) { s_ao[t] = o; s_aoff[t] = ao; o += s_am[t]; ao += (long long)s_am[t] * s_am[t] + s_am[t]; }
+    if (so >= 0) { s_am[J] = m; s_ao[J] = P; s_aoff[J] = 0; }
   }
   __syncthreads();
   const double *N = A.panels + B.panel_off;
   double *rec = A.acc + B.acc_off;
-  const int ntask = s_t0[J + 1], ns = (m + 3) >> 2;
+  const int ns = (m + 3) >> 2;
   const int nch = A.no_fwd ? 0 : B.ndch;
-  for (int e = wid; e < ntask; e += NT / 64) {
-    int t = 0;
-    while (e >= s_t0[t + 1]) ++t;
-    int it = 0, pe = e - s_t0[t];
-    while ((it + 1) * (it + 2) / 2 <= pe) ++it;
-    const int jt = pe - it * (it + 1) / 2;
+  const int JJ = J + (so >= 0 ? 1 : 0);
+  // Round 3: the children's forwarded parts requested four children at a time (one round trip per tile instead of one per child),
+  // the mirrored tile -- where a reader wants both triangles at all: A.mirror -- through LDS, so that its store runs along rows like
+  // the tile's own (lane = column made every mirrored store 64 scattered sectors: 1.4 of the 6.8 ms this kernel took at config #4).
+  // Same operands, same K order, same order of the children: bit-identical records.  (Staging an ancestor's slice of the panel
+  // in LDS, so that the tiles stop re-reading it from L2, measured SLOWER: 48 KB per workgroup, two workgroups per CU.)
+  int tbase = 0;   // tiles of the ancestors before t: the block's tiles are dealt over the waves as ONE sequence
+  for (int t = 0; t < JJ; ++t) {
     const int ma = s_am[t], oa = s_ao[t];
-    const int ci = 16 * it + l15, cj = 16 * jt + l15;
-    const double *ap = N + (size_t)l4 * ld + oa + min(ci, ma - 1), *bp = N + (size_t)l4 * ld + oa + min(cj, ma - 1);
-    d4 c = (d4){0.0, 0.0, 0.0, 0.0};
-    int st = 0;
-    for (; st + 4 <= ns; st += 4) {   // eight operand loads in flight per lane
-      double a4[4], b4[4];
+    const bool isS0 = t == J;
+    const int nt = (ma + 15) >> 4, ntask = nt * (nt + 1) / 2;
+    double *out = isS0 ? A.s0 + so : rec + s_aoff[t];
+    const int e0 = (wid - tbase % (NT / 64) + (NT / 64)) % (NT / 64);
+    tbase += ntask;
+    for (int e = e0; e < ntask; e += NT / 64) {
+      int it = 0;
+      while ((it + 1) * (it + 2) / 2 <= e) ++it;
+      const int jt = e - it * (it + 1) / 2;
+      const int ci = 16 * it + l15, cj = 16 * jt + l15;
+      d4 c = (d4){0.0, 0.0, 0.0, 0.0};
+      {
+        const double *ap = N + (size_t)l4 * ld + oa + min(ci, ma - 1), *bp = N + (size_t)l4 * ld + oa + min(cj, ma - 1);
+        int st = 0;
+        for (; st + 4 <= ns; st += 4) {   // eight operand loads in flight per lane
+          double a4[4], b4[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool rok = 4 * (st + q) + l4 < m;
-        a4[q] = (rok && ci < ma) ? ap[(size_t)4 * (st + q) * ld] : 0.0;
-        b4[q] = (rok && cj < ma) ? bp[(size_t)4 * (st + q) * ld] : 0.0;
+          for (int q = 0; q < 4; ++q) {
+            const bool rok = 4 * (st + q) + l4 < m;
+            a4[q] = (rok && ci < ma) ? ap[(size_t)4 * (st + q) * ld] : 0.0;
+            b4[q] = (rok && cj < ma) ? bp[(size_t)4 * (st + q) * ld] : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
+        }
+        for (; st < ns; ++st) {
+          const bool rok = 4 * st + l4 < m;
+          const double a1 = (rok && ci < ma) ? ap[(size_t)4 * st * ld] : 0.0, b1 = (rok && cj < ma) ? bp[(size_t)4 * st * ld] : 0.0;
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+        }
+      }
+      // C layout: entry (i = 16 it + 4 q + l4, j = 16 jt + l15); the children's parts, four children at a time, in child order
+      double v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = c[q];
+      if (!isS0) {
+        for (int c0 = 0; c0 < nch; c0 += 4) {
+          double x[4][4];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int ch = min(c0 + cc, nch - 1);
+            const long long co = ch < 16 ? s_choff[ch] : A.blks[A.dch_idx[B.dch_ptr + ch]].acc_off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = 16 * it + 4 * q + l4;
+              x[cc][q] = (c0 + cc < nch && i < ma && cj < ma) ? A.acc[co + s_aoff[t] + (size_t)i * ma + cj] : 0.0;
+            }
+          }
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (c0 + cc < nch) v[q] += x[cc][q];
+        }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a4[q], b4[q], c, 0, 0, 0);
-    }
-    for (; st < ns; ++st) {
-      const bool rok = 4 * st + l4 < m;
-      const double a1 = (rok && ci < ma) ? ap[(size_t)4 * st * ld] : 0.0, b1 = (rok && cj < ma) ? bp[(size_t)4 * st * ld] : 0.0;
-      c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-    }
-    // C layout: entry (i = 16 it + 4 q + l4, j = 16 jt + l15); the mirrored entry of an off-diagonal tile gets the same value
-    const bool isS0 = t == J;
-    double *out = isS0 ? A.s0 + so : rec + s_aoff[t];
+      for (int q = 0; q < 4; ++q) {
+        const int i = 16 * it + 4 * q + l4;
+        if (i < ma && cj < ma) out[(size_t)i * ma + cj] = v[q];
+      }
+      if (A.mirror && it != jt) {   // the mirrored tile (jt, it): transposed through LDS, stored along its rows
+        double *tr = s_tr[wid];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = 16 * it + 4 * q + l4, j = cj;
-      if (i < ma && j < ma) {
-        double v = c[q];
-        if (!isS0) {
-          for (int ch = 0; ch < nch; ++ch) {
-            const long long co = ch < 16 ? s_choff[ch] : A.blks[A.dch_idx[B.dch_ptr + ch]].acc_off;
-            v += A.acc[co + s_aoff[t] + (size_t)i * ma + j];
-          }
+        for (int q = 0; q < 4; ++q) tr[(4 * q + l4) * 17 + l15] = v[q];   // tr[i'][j'] = tile entry (i', j')
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its LDS operations execute in order)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jr = 16 * jt + 4 * q + l4, ic = 16 * it + l15;   // mirrored entry (jr, ic) = tile entry (ic', jr') = tr[l15][4 q + l4]
+          if (jr < ma && ic < ma) out[(size_t)jr * ma + ic] = tr[l15 * 17 + 4 * q + l4];
         }
-        out[(size_t)i * ma + j] = v;
-        if (it != jt) out[(size_t)j * ma + i] = v;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     }
   }

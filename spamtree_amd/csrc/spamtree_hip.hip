@@ -1931,6 +1931,11 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
           std::memset(&Gb, 0, sizeof(Gb));
           Gb.blks = h->d_blks.p; Gb.anc_idx = h->d_anc.p; Gb.dch_idx = h->d_dch.p; Gb.list = A.list; Gb.nlist = A.nlist;
           Gb.panels = A.panels; Gb.acc = A.acc; Gb.s0 = A.s0; Gb.s0off = A.s0off; Gb.no_fwd = A.no_fwd;
+          // both triangles unless every level of the tree is read by k_gram_big / the generic sweep's cached branch (tiles it >= jt /
+          // the lower triangle only)
+          bool all_big = true;
+          for (const auto &L2 : h->levels) all_big = all_big && (L2.count == 0 || L2.big_sample);
+          Gb.mirror = all_big ? 0 : 1;
           hipLaunchKernelGGL(k_gram_big, dim3(A.nlist), dim3(NT), 0, h->stream, Gb);
           A.do_gram = 0;
         }
