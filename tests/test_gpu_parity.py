@@ -45,6 +45,9 @@ CASES = [
     # config #5 AS SPECIFIED (BASELINE.json configs[4]; NA census spamtree_model.cpp:303-313, quirk Q3 :1375): outcomes dropped
     # with probabilities 10 / 30 / 50 %, q = 3, cell_size = 9, the NA rows in their own prediction level
     dict(side=24, q=3, missing=(0.1, 0.3, 0.5), cell_size=9),
+    # the default cell size with the same imbalanced pattern: wide blocks of unequal widths (siblings no longer share a row stride,
+    # chains of odd lengths) on k_factor_lchain + k_factor_ref_finish and the generic sweep kernel
+    dict(side=30, q=3, missing=(0.1, 0.3, 0.5)),
     # unusual trees: 3 x 2 branching, small cells, a finite depth with a nearest-neighbour leftover level
     dict(side=30, q=1, missing=0.1, cell_size=9, K=(3, 2)),
     dict(side=30, q=1, missing=0.0, tree_depth=2),
