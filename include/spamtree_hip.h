@@ -91,6 +91,14 @@ int st_get_xb(st_handle h, double *xb);                    /* n_all */
  * slot 0 = param_data, 1 = alter_data.  Returns 0 (the reference's `true`) or 1/2/3 (`false`, errtype);
  * *loglik = data.loglik_w (undefined on failure).  theta has ntheta = 3q + (q>2?3:1) + q(q-1)/2 entries. */
 int st_factor(st_handle h, int slot, const double *theta, int ntheta, double *loglik);
+/* st_factor in two halves: _enqueue starts the work (one GPU: every launch and the copy of the results; with a communicator
+ * attached: nothing yet), _finish waits and returns what st_factor returns.  In between the caller may issue calls that do not
+ * touch the slot -- the C++ driver draws tausq / beta from the sweep's statistics and uploads them (st_tausq_stats, st_beta_stats,
+ * st_set_tausq_inv, st_set_beta: none of them waits for the main stream), so that the Metropolis step's host round trip
+ * (src/spamtree_fit.cpp:232-262, then :308-330) is the only one of the iteration.  No st_swap / st_sample_w* in between. */
+int st_factor_enqueue(st_handle h, int slot, const double *theta, int ntheta);
+int st_factor_is_async(st_handle h);   /* 1: _enqueue really starts the work (one GPU, no communicator) */
+int st_factor_finish(st_handle h, double *loglik);
 /* optional: start phase A of the latency-bound top levels ahead of time -- they depend on theta only (their blocks'
  * quadratic forms are redone with the current w afterwards) -- on a second stream, e.g. before the sweep; the next
  * st_factor / st_factor_local for the same slot and theta picks the result up.  Identical results; a no-op when the tree

@@ -66,6 +66,9 @@ SIGNATURES = {
     "st_shard_plan_opt": (C.c_int, [C.POINTER(StProblem), C.POINTER(StOptions), C.c_int32, c_ip, C.POINTER(C.c_int32)]),
     "st_shard_info": (C.c_int, [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_ip, c_ip]),
     "st_factor_local": (C.c_int, [H, C.c_int, c_dp, C.c_int]),
+    "st_factor_enqueue": (C.c_int, [H, C.c_int, c_dp, C.c_int]),
+    "st_factor_finish": (C.c_int, [H, c_dp]),
+    "st_factor_is_async": (C.c_int, [H]),
     "st_loglik_local": (C.c_int, [H, C.c_int]),
     "st_mg_pack_comps": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), c_ip]),
     "st_mg_finish": (C.c_int, [H, c_dp]),

@@ -157,6 +157,7 @@ struct stm_chain_s {
   int adapting = 1, sample_beta = 1, sample_tausq = 1, sample_theta = 1, sample_w = 1;
   long long m = 0;
   int last_accepted = 0, last_acceptable = 1;
+  bool tb_drawn = false;   // this iteration's tausq / beta were drawn under the proposal's factorisation already
   double last_logaccept = 0;
   bool initialised = false;
 };
@@ -223,7 +224,9 @@ extern "C" int stm_init(stm_chain c) {
 }
 
 // spamtree_fit.cpp:183-289 : w sweep, its log-density, Metropolis step for theta
-static int step_w_theta(stm_chain c) {
+static int draw_tausq_beta(stm_chain c);
+// early_ok: nothing that changes w (a prediction on a saved iteration: :300-306) will run between this step and the tausq / beta draws
+static int step_w_theta(stm_chain c, bool early_ok = true) {
   const uint32_t m = (uint32_t)c->m;
   int rc;
   const int k = c->k;
@@ -270,6 +273,23 @@ static int step_w_theta(stm_chain c) {
   if (c->sample_theta) {
     c->theta_alt = np;
     double new_ll = c->loglik[1];
+    // The tausq / beta draws of this iteration (:308-330) need the sweep's statistics only -- not the Metropolis outcome -- and
+    // their streams are counter-based: they are made HERE, while the GPU factorises the proposal (the statistics ran on the
+    // second stream at its start), and their uploads and the XB update queue behind phase A.  After the Metropolis step the
+    // next sweep can be enqueued at once; before, two more host round trips (statistics -> draw -> upload, twice) stood between
+    // the end of phase A and the next kernel: ~50 us of idle GPU per iteration (SPAMTREE_EARLY_BETA=0: the old order; same chain).
+    // Not on iterations whose prediction step runs in between: with quirk Q3 the beta statistics pair y with w of ALL rows
+    // (spamtree_model.cpp:1375), i.e. they see the predicted values.
+    static const bool early = !(getenv("SPAMTREE_EARLY_BETA") && getenv("SPAMTREE_EARLY_BETA")[0] == '0');
+    if (early && early_ok && c->sample_w && st_factor_is_async(c->h)) {
+      rc = st_factor_enqueue(c->h, 1, np.data(), k);
+      if (rc == 0) {
+        const int r3 = draw_tausq_beta(c);
+        c->tb_drawn = true;
+        rc = st_factor_finish(c->h, &new_ll);
+        if (r3) return r3;
+      }
+    } else
     rc = st_factor(c->h, 1, np.data(), k, &new_ll);
     if (sweep_open) {
       const int r2 = finish_sweep();   // (a failed sweep outranks whatever the factorisation of the proposal made of its w)
@@ -306,7 +326,7 @@ static int step_w_theta(stm_chain c) {
 }
 
 // spamtree_fit.cpp:308-330 with the host parts of gibbs_sample_tausq (:1393-1417) and gibbs_sample_beta (:1364-1391)
-static int step_tausq_beta(stm_chain c) {
+static int draw_tausq_beta(stm_chain c) {
   const uint32_t m = (uint32_t)c->m;
   const int p = c->p, q = c->q;
   int rc;
@@ -338,6 +358,11 @@ static int step_tausq_beta(stm_chain c) {
     }
     if ((rc = st_set_beta(c->h, c->Bcoeff.data())) != 0) { c->err = st_last_error(c->h); return rc; }
   }
+  return ST_OK;
+}
+static int step_tausq_beta(stm_chain c) {
+  if (!c->tb_drawn) { const int rc = draw_tausq_beta(c); if (rc) return rc; }   // (else: drawn under the proposal's factorisation, step_w_theta)
+  c->tb_drawn = false;
   c->m += 1;
   return ST_OK;
 }
@@ -387,7 +412,7 @@ extern "C" int spamtree_mv_mcmc_c(const st_problem *pb, const st_options *opt, c
   for (long long m = 0; m < mcmc && rc == 0; ++m) {
     const long long mx = m - mcmc_burn;
     const bool saving = mx >= 0 && (mx % mcmc_thin == 0);
-    rc = step_w_theta(c);
+    rc = step_w_theta(c, !(saving && sample_predicts && c->sample_w));
     if (rc) break;
     if (saving && sample_predicts && c->sample_w) {                    // :300-306
       int need_update = 0;

@@ -167,6 +167,12 @@ struct st_handle_s {
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
   std::vector<double> host_stats;
   double *pin = nullptr;                      // 64 doubles of pinned host memory for the small device-to-host reads
+  double *pin_up = nullptr;                   // pinned staging of the small per-iteration uploads (beta, tausq_inv): two slots taken in turn,
+  int pin_up_slot = 0, pin_up_len = 0;        // so that the copy is truly asynchronous and the setters need no host synchronisation
+  hipEvent_t ev_up[2] = {nullptr, nullptr};   // recorded behind a slot's copy: a slot is rewritten only after its last copy has run
+  bool factor_open = false; int factor_open_slot = 0;   // st_factor_enqueue without its st_factor_finish yet
+  std::vector<double> top_theta_open;                   // ... its theta where the work itself waits for st_factor_finish (communicator attached)
+  hipEvent_t ev_factor = nullptr;                       // behind the copies of an enqueued factorisation's sums and failure word
   std::vector<char> s0_valid;                 // per level: d_s0 holds the theta-only precision parts of the accepted theta (column-group levels)
   bool gram_valid = false;                    // message Gram parts in `acc` match the accepted theta (slot 0)
   bool cache_gram = true;
@@ -311,6 +317,9 @@ extern "C" int st_destroy(st_handle h) {
   for (auto e : h->ev_free) (void)hipEventDestroy(e);
   if (h->comm) (void)ncclCommDestroy(h->comm);
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->pin_up) (void)hipHostFree(h->pin_up);
+  for (int i = 0; i < 2; ++i) if (h->ev_up[i]) (void)hipEventDestroy(h->ev_up[i]);
+  if (h->ev_factor) (void)hipEventDestroy(h->ev_factor);
   if (h->stream && !h->ext_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return ST_OK;
@@ -1015,6 +1024,10 @@ static int create_impl(const st_problem *pb, const st_options *opt, st_handle *o
   } while (0)
   CCHK(hipStreamCreate(&h->stream));
   CCHK(hipHostMalloc((void **)&h->pin, 64 * sizeof(double), hipHostMallocDefault));
+  h->pin_up_len = QMAX + std::max(1, h->p * h->q);
+  CCHK(hipHostMalloc((void **)&h->pin_up, (size_t)2 * h->pin_up_len * sizeof(double), hipHostMallocDefault));
+  for (int i = 0; i < 2; ++i) CCHK(hipEventCreateWithFlags(&h->ev_up[i], hipEventDisableTiming));
+  CCHK(hipEventCreateWithFlags(&h->ev_factor, hipEventDisableTiming));
   CCHK(h->d_cx.upload(cx)); CCHK(h->d_cy.upload(cy)); CCHK(h->d_y.upload(y)); CCHK(h->d_X.upload(X));
   CCHK(h->d_mv.upload(mv)); CCHK(h->d_obs.upload(obs)); CCHK(h->d_partner.upload(partner));
   CCHK(h->d_dev2model.upload(h->dev2model));
@@ -1327,22 +1340,33 @@ extern "C" int st_set_beta(st_handle h, const double *Bcoeff) {
   if (!h || !Bcoeff) return ST_ERR_USAGE;
   invalidate_stats(h);
   HCHK(h, hipSetDevice(h->device));
-  HCHK(h, hipMemcpyAsync(h->d_B.p, Bcoeff, (size_t)h->p * h->q * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // through the handle's pinned staging (the caller's buffer is free on return; a slot is rewritten only after its last copy
+  // has run): NO host synchronisation -- the C++ driver calls the setters while the proposal's factorisation is still running
+  // (st_factor_enqueue / st_factor_finish), so that the new XB is in place the moment phase A ends
+  h->pin_up_slot ^= 1;
+  HCHK(h, hipEventSynchronize(h->ev_up[h->pin_up_slot]));
+  double *stg = h->pin_up + (size_t)h->pin_up_slot * h->pin_up_len + QMAX;
+  std::memcpy(stg, Bcoeff, (size_t)h->p * h->q * sizeof(double));
+  HCHK(h, hipMemcpyAsync(h->d_B.p, stg, (size_t)h->p * h->q * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HCHK(h, hipEventRecord(h->ev_up[h->pin_up_slot], h->stream));
   {
     ProfScope ps(h, 4);
     const int grid = (int)((h->n_all + NT - 1) / NT);
     hipLaunchKernelGGL(k_xb, dim3(grid), dim3(NT), 0, h->stream, h->d_X.p, h->d_mv.p, h->d_B.p, h->n_all, h->p, h->d_xb.p);
   }
   HCHK(h, hipGetLastError());
-  HCHK(h, hipStreamSynchronize(h->stream));
   return ST_OK;
 }
 extern "C" int st_set_tausq_inv(st_handle h, const double *t) {
   if (!h || !t) return ST_ERR_USAGE;
   for (int j = 0; j < h->q; ++j) h->tausq_inv[j] = t[j];
   HCHK(h, hipSetDevice(h->device));
-  HCHK(h, hipMemcpyAsync(h->d_tsq.p, h->tausq_inv, QMAX * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HCHK(h, hipStreamSynchronize(h->stream));
+  h->pin_up_slot ^= 1;                                      // (pinned staging, no host synchronisation: st_set_beta)
+  HCHK(h, hipEventSynchronize(h->ev_up[h->pin_up_slot]));
+  double *stg = h->pin_up + (size_t)h->pin_up_slot * h->pin_up_len;
+  std::memcpy(stg, h->tausq_inv, QMAX * sizeof(double));
+  HCHK(h, hipMemcpyAsync(h->d_tsq.p, stg, QMAX * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HCHK(h, hipEventRecord(h->ev_up[h->pin_up_slot], h->stream));
   return ST_OK;
 }
 // readers of a slot's arena while st_factor_begin's launches may still be writing it on the second stream: order the
@@ -1701,6 +1725,23 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
     if (rc) return rc;
     return exchange_comps_and_finish(h, slot, loglik);
   }
+  int rc = st_factor_enqueue(h, slot, theta, ntheta);
+  if (rc) return rc;
+  return st_factor_finish(h, loglik);
+}
+// st_factor in two halves (one GPU): everything is ENQUEUED by the first -- the levels, the two sums, the copies of the sums and of
+// the failure word to pinned memory, an event behind them -- and the second waits for that event and reads them.  In between the
+// host may enqueue work that does not touch the proposal's slot: the C++ driver draws tausq and beta from the sweep's statistics
+// (ready early in phase A: they run on the second stream) and uploads them, so that XB is current when phase A ends instead of
+// two host round trips later.  With a communicator attached the first half enqueues nothing and the second does all of st_factor.
+extern "C" int st_factor_is_async(st_handle h) { return (h && !(h->world > 1 || h->comm)) ? 1 : 0; }
+extern "C" int st_factor_enqueue(st_handle h, int slot, const double *theta, int ntheta) {
+  if (!h || !theta || slot < 0 || slot > 1) return ST_ERR_USAGE;
+  if (h->factor_open) { h->err = "st_factor_enqueue: the previous one has not been finished"; return ST_ERR_USAGE; }
+  if (h->world > 1 || h->comm) {
+    h->factor_open = true; h->factor_open_slot = slot; h->top_theta_open.assign(theta, theta + ntheta);
+    return ST_OK;
+  }
   int rc = st_factor_local(h, slot, theta, ntheta);
   if (rc) return rc;
   // the failure word and the two sums come back in ONE synchronisation (the sums are meaningless after a failure)
@@ -1710,12 +1751,27 @@ extern "C" int st_factor(st_handle h, int slot, const double *theta, int ntheta,
     launch_sum2(h->stream, h->d_logdet[phys].p, h->d_loglik[phys].p, (int)h->n_blocks, h->d_scalars.p + 8, h->d_scalars.p);
   }
   HCHK(h, hipGetLastError());
-  HCHK(h, hipMemcpyAsync(h->pin, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HCHK(h, hipMemcpyAsync(h->pin + 2, h->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HCHK(h, hipStreamSynchronize(h->stream));
-  const int e0 = ((const int *)(h->pin + 2))[0];
+  HCHK(h, hipMemcpyAsync(h->pin + 12, h->d_scalars.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipMemcpyAsync(h->pin + 14, h->d_err.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HCHK(h, hipEventRecord(h->ev_factor, h->stream));
+  h->factor_open = true; h->factor_open_slot = slot; h->top_theta_open.clear();
+  return ST_OK;
+}
+extern "C" int st_factor_finish(st_handle h, double *loglik) {
+  if (!h) return ST_ERR_USAGE;
+  if (!h->factor_open) { h->err = "st_factor_finish without st_factor_enqueue"; return ST_ERR_USAGE; }
+  h->factor_open = false;
+  if (h->world > 1 || h->comm) {
+    if (!h->comm) { h->err = "world > 1: call st_comm_init first, or use st_factor_local / st_mg_pack_comps / (all-reduce) / st_mg_finish"; return ST_ERR_USAGE; }
+    int rc = st_factor_local(h, h->factor_open_slot, h->top_theta_open.data(), (int)h->top_theta_open.size());
+    if (rc) return rc;
+    return exchange_comps_and_finish(h, h->factor_open_slot, loglik);
+  }
+  HCHK(h, hipSetDevice(h->device));
+  HCHK(h, hipEventSynchronize(h->ev_factor));
+  const int e0 = ((const int *)(h->pin + 14))[0];
   if (e0 != INT_MAX) return e0 & 15;  // the reference's `return false` (:971-982); deeper levels hold unspecified values (Q5)
-  if (loglik) *loglik = h->pin[0] + h->pin[1];   // loglik_w = logdetCi + sum(loglik_w_comps)  (:987-988)
+  if (loglik) *loglik = h->pin[12] + h->pin[13];   // loglik_w = logdetCi + sum(loglik_w_comps)  (:987-988)
   return ST_OK;
 }
 

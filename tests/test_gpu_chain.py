@@ -144,7 +144,8 @@ def test_deferred_sweep_protocol_failure_and_misuse():
 
 
 def test_chain_with_and_without_deferred_sync_are_identical():
-    """SPAMTREE_DEFER_SYNC is read once per process, so the two settings run in subprocesses: same chain bit for bit."""
+    """SPAMTREE_DEFER_SYNC and SPAMTREE_EARLY_BETA (the tausq / beta draws made under the proposal's factorisation:
+    st_factor_enqueue / st_factor_finish) are read once per process, so the settings run in subprocesses: same chain bit for bit."""
     import os
     import subprocess
     import sys
@@ -157,8 +158,44 @@ def test_chain_with_and_without_deferred_sync_are_identical():
             "ch.step(40); st = ch.state()\n"
             "print(repr((st['theta'].tolist(), st['tausq_inv'].tolist(), st['loglik'], float(np.sum(ch.get_w())))))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for flag in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPAMTREE_DEFER_SYNC=flag), capture_output=True, text=True, timeout=600)
+    for defer, early in (("1", "1"), ("0", "1"), ("1", "0")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPAMTREE_DEFER_SYNC=defer, SPAMTREE_EARLY_BETA=early),
+                           capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_factor_in_two_halves_equals_st_factor():
+    """st_factor_enqueue / st_factor_finish (include/spamtree_hip.h): the same return code and log-density as st_factor, with the
+    setters -- which no longer synchronise the host -- called in between; misuse is refused."""
+    import ctypes as C
+    from tests.test_gpu_parity import hip_model
+    pb = make_problem(side=25, q=1, seed=4, missing=0.1)
+    rng = np.random.default_rng(1)
+    w0 = rng.standard_normal(pb["n"])
+    hm = hip_model(pb, w=w0, tausq=0.2)
+    assert hm.get_loglik_comps_w(0)
+    lib, h = hm.lib, hm.h
+    dp = C.POINTER(C.c_double)
+    th = np.ascontiguousarray(pb["theta"] * 1.1)
+    ll0, ll1 = C.c_double(), C.c_double()
+    assert lib.st_factor(h, 1, th.ctypes.data_as(dp), th.size, C.byref(ll0)) == 0
+    assert lib.st_factor_finish(h, C.byref(ll1)) < 0                      # nothing enqueued
+    assert lib.st_factor_enqueue(h, 1, th.ctypes.data_as(dp), th.size) == 0
+    assert lib.st_factor_enqueue(h, 1, th.ctypes.data_as(dp), th.size) < 0   # a second one before the first is finished
+    t2 = np.array([1.0 / 0.3]); b2 = np.full(pb["p"], 0.25)
+    assert lib.st_set_tausq_inv(h, t2.ctypes.data_as(dp)) == 0 and lib.st_set_beta(h, b2.ctypes.data_as(dp)) == 0
+    t2[:] = -1.0; b2[:] = 99.0                                               # the caller's buffers are free on return
+    assert lib.st_factor_finish(h, C.byref(ll1)) == 0 and ll1.value == ll0.value
+    bad = th.copy(); bad[0] = -1.0                                           # a failing proposal: the reference's errtype through _finish
+    assert lib.st_factor_enqueue(h, 1, bad.ctypes.data_as(dp), bad.size) == 0
+    assert lib.st_factor_finish(h, C.byref(ll1)) in (1, 2, 3)
+    # the uploads arrived: a sweep with the new tausq / beta equals one on a fresh handle that was given them up front
+    z = rng.standard_normal(pb["n"])
+    hm.deal_with_w(z)
+    hr = hip_model(pb, w=w0, tausq=0.3, beta=np.full(pb["p"], 0.25))
+    assert hr.get_loglik_comps_w(0)
+    hr.deal_with_w(z)
+    assert np.array_equal(hm.get_w(), hr.get_w())
+    hm.close(); hr.close()
