@@ -166,7 +166,8 @@ struct st_handle_s {
   bool stats_valid = false;                   // d_stats matches the current w and XB
   bool host_stats_valid = false;              // ... and host_stats holds a copy of it
   std::vector<double> host_stats;
-  double *pin = nullptr;                      // 64 doubles of pinned host memory for the small device-to-host reads
+  double *pin = nullptr;                      // 64 doubles of pinned host memory for the small device-to-host reads: [0..3] st_factor (comm path) /
+                                              // st_loglik_w sums + failure word, [8..11] st_sample_w_loglik_end, [12..15] st_factor_enqueue / _finish, [20..] statistics
   double *pin_up = nullptr;                   // pinned staging of the small per-iteration uploads (beta, tausq_inv): two slots taken in turn,
   int pin_up_slot = 0, pin_up_len = 0;        // so that the copy is truly asynchronous and the setters need no host synchronisation
   hipEvent_t ev_up[2] = {nullptr, nullptr};   // recorded behind a slot's copy: a slot is rewritten only after its last copy has run
