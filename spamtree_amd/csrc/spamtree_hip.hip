@@ -1975,8 +1975,9 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
           else if (h->leaf_seg && need <= 6 && L.maxMa <= 32) hipLaunchKernelGGL((k_sample_leaf_seg<6>), dim3(L.gown_n), dim3(NT), ((size_t)4 * 64 * 6 + 3 * 32) * 8, h->stream, F);
           else hipLaunchKernelGGL(k_sample_leaf, dim3(L.gown_n), dim3(NT), ((size_t)L.maxP + 32 + 4 * 256 + 3 * 32) * 8, h->stream, F);
         }
-        else if (h->sample_wave && L.maxM <= 27 && (h->sample_wave == 2 || L.gown_n >= 32 * h->sm_count)) {   // one block per wave: 10 % faster on a level
-          // that keeps every CU busy for many rounds (n = 1e6, level 7: 0.48 -> 0.43 ms), slower on latency-bound small levels: gd | wv | seg | tv, ev | Ri, per wave
+        else if (h->sample_wave && L.maxM <= 27 && (h->sample_wave == 2 || L.gown_n >= 8 * h->sm_count)) {   // one block per wave: faster on a level
+          // that keeps every CU busy for several rounds (n = 1e6 after the row-wise panel pass: level 7 0.44 -> 0.35 ms, level 6 -- 4096 blocks --
+          // 0.151 -> 0.117), a wash at 1024 blocks (0.050 -> 0.046 there, 0.034 -> 0.039 at config #5), slower on latency-bound small levels (256 blocks: 0.029 -> 0.040): gd | wv | seg | tv, ev | Ri, per wave
           const size_t per = (((size_t)h->gd_stride + L.maxP + 32 + L.av_dbl + 64 + (size_t)std::max(L.maxM, 1) * CH_LD + 1) & ~(size_t)1);
           F.ldN = (int)per; F.Mrows = L.maxM;
           hipLaunchKernelGGL(k_sample_wave, dim3((L.gown_n + NT / 64 - 1) / (NT / 64)), dim3(NT), per * 8 * (NT / 64), h->stream, F);
