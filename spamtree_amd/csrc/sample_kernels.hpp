@@ -1117,7 +1117,13 @@ __global__ __launch_bounds__(NT, 4) void k_gram_direct(SampleFastArgs A) {
 // LDS holds vectors only (plus the m x m posterior precision of reference blocks): ~6-19 KB instead of 50-55 KB, so
 // 6-8 workgroups share a CU and their latency chains overlap.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
+// LAT (round 3, levels that do not fill the chip: a block there is a CHAIN of dependent round trips -- descriptor, rows' data, w + Ri,
+// two batches of pass 1, the cached precision, the children's vectors, four batches of pass 2: about thirteen -- and the level takes
+// as long as one block): every global load that needs the descriptor only is requested at once and parked in registers -- pass 2's
+// rows by the threads of waves 1-3, over the draw --, so that three round trips are left.  Same arithmetic in the same order
+// (identical draws); 256 registers per thread instead of 102, which costs occupancy the small levels do not use.
+template <bool LAT>
+__global__ __launch_bounds__(NT, LAT ? 2 : 5) void k_sample_lean(SampleFastArgs A) {
   extern __shared__ double lds[];
   __shared__ int s_am[MAXJ], s_ao[MAXJ + 1];
   __shared__ long long s_arow[MAXJ], s_aoff[MAXJ + 1];
@@ -1147,6 +1153,90 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
   const int M = G.M, P = G.P, J = B0.nanc;
   const bool refgrp = B0.isref != 0;
   if (tid == 0) { s_fail = 0; s_nch = B0.ndch; }
+  const long long so = (refgrp && A.s0off && A.s0_mode) ? A.s0off[B0.blk0] : -1;
+  const bool s0_load = so >= 0 && A.s0_mode == 2;
+  double xq[28], x2[28], ch2[4], s0v[3], smv[4];   // LAT: pass 1's segment, pass 2's column, its children's vectors, the cached precision
+  const int k2 = tid - 64;                           // LAT: pass 2's chain column of this thread (waves 1-3; columns beyond 191: late)
+  const int nch2 = A.no_fwd ? 0 : B0.ndch;
+  if constexpr (LAT) {
+    double t_ = 0.0, y_ = 0.0, xb_ = 0.0, z_ = 0.0, r_ = 0.0;
+    int mv_ = 0;
+    const bool rowthr = tid >= 32 && tid < 64 && tid - 32 < M;
+    if (tid >= 32 && tid < 64) {
+      const int j = tid - 32;
+      int bi = 0;
+      long long ro = 0;
+      if (j < M) {
+        const long long r = G.row0 + j;
+        mv_ = A.mv[r]; y_ = A.y[r]; xb_ = A.xb[r]; z_ = A.z[r];
+        const long long *gb = s_gd + 8 + 4 * J;   // per block: panel offset, first row, ld
+        while (bi + 1 < G.nblk && r >= gb[3 * (bi + 1) + 1]) ++bi;
+        ro = gb[3 * bi] + (r - gb[3 * bi + 1]) * gb[3 * bi + 2];
+        if (!refgrp) r_ = A.panels[ro + P];
+      }
+      s_cb[j] = bi; s_rowoff[j] = ro;
+    }
+    lds_barrier();   // (LDS only: the loads above stay in flight)
+    // everything else that needs the descriptor only
+    double wreg = 0.0;
+    int wk = -1;
+    if (tid < P) {
+      int t = 0;
+      while (t + 1 < J && tid >= s_ao[t + 1]) ++t;
+      wk = tid; wreg = A.w[s_arow[t] + (tid - s_ao[t])];
+    }
+    double rireg[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int idx = tid + NT * e, i = idx / M, j = idx - i * M;
+      rireg[e] = (refgrp && idx < M * M && j <= i) ? A.panels[s_rowoff[i] + P + j] : 0.0;
+    }
+    {
+      const int idx = tid, mj = M * J;   // pass 1: thread (row r, ancestor t)
+      const int ii = mj > 0 ? min(idx, mj - 1) : 0, r = J ? ii / J : 0, t = J ? ii - r * J : 0;
+      const int ma = J ? s_am[t] : 0;
+      const double *row = A.panels + s_rowoff[r] + (J ? s_ao[t] : 0);
+#pragma unroll
+      for (int jj = 0; jj < 28; ++jj) xq[jj] = (idx < mj && jj < ma) ? row[jj] : 0.0;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      smv[cc] = (refgrp && tid < M && cc < B0.ndch) ? A.acc[s_coff[min(cc, max(B0.ndch - 1, 0))] + B0.acc_len + M * M + tid] : 0.0;
+    if (k2 >= 0 && k2 < P) {   // pass 2: every row of the group at column k2, and the children's vectors for it
+      int t = 0;
+      while (t + 1 < J && k2 >= s_ao[t + 1]) ++t;
+      const int ma = s_am[t], i = k2 - s_ao[t];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ch2[cc] = (cc < nch2) ? A.acc[s_coff[min(cc, max(nch2 - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
+#pragma unroll
+      for (int rr = 0; rr < 28; ++rr) x2[rr] = (rr < M) ? A.panels[s_rowoff[min(rr, M - 1)] + k2] : 0.0;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {   // (last: they wait for `so`, itself a load behind the descriptor)
+      const int idx = tid + NT * e, i = idx / M, j = idx - i * M;
+      s0v[e] = (s0_load && idx < M * M && j <= i) ? A.s0[so + idx] : 0.0;
+    }
+    if (rowthr) t_ = A.tausq_inv[mv_];
+    if (tid >= 32 && tid < 64) { const int j = tid - 32; tsq[j] = t_; yx[j] = y_ - xb_; zc[j] = z_; rjv[j] = r_; }
+    if (wk >= 0) wv[wk] = wreg;
+    for (int k = NT + tid; k < P; k += NT) {   // (chains of more than 256 rows)
+      int t = 0;
+      while (t + 1 < J && k >= s_ao[t + 1]) ++t;
+      wv[k] = A.w[s_arow[t] + (k - s_ao[t])];
+    }
+    if (refgrp) {
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int idx = tid + NT * e, i = idx / M, j = idx - i * M;
+        if (idx < M * M) Rc[i * CH_LD + j] = rireg[e];
+      }
+      for (int idx = 3 * NT + tid; idx < M * M; idx += NT) {   // (groups of more than 27 rows)
+        const int i = idx / M, j = idx - i * M;
+        Rc[i * CH_LD + j] = (j <= i) ? A.panels[s_rowoff[i] + P + j] : 0.0;
+      }
+    }
+    __syncthreads();
+  } else {
   if (tid >= 32 && tid < 64) {
     const int j = tid - 32;
     double t_ = 0.0, y_ = 0.0, z_ = 0.0, r_ = 0.0;
@@ -1175,6 +1265,7 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
     }
   }
   __syncthreads();
+  }
   // ---- pass 1: segment sums seg[t][r] = sum_j N[r][oa_t + j] w_a[j]
   for (int idx = tid; idx < M * J; idx += NT) {
     const int r = idx / J, t = idx - r * J;
@@ -1182,6 +1273,10 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
     const double *row = A.panels + s_rowoff[r] + oa;
     const double *wa = wv + oa;
     double a = 0.0;
+    if (LAT && idx == tid && ma <= 28) {   // the segment is in registers (same products, same order; the zero tail adds nothing)
+#pragma unroll
+      for (int jj = 0; jj < 28; ++jj) a += xq[jj] * ((jj < ma) ? wa[jj] : 0.0);
+    } else
     for (int j0 = 0; j0 < ma; j0 += 16) {   // two batches of loads for the usual 25-row ancestor
       double x[16];
 #pragma unroll
@@ -1199,13 +1294,11 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
   }
   __syncthreads();
   if (refgrp) {
-    const long long so = (A.s0off && A.s0_mode) ? A.s0off[B0.blk0] : -1;
-    const bool s0_load = so >= 0 && A.s0_mode == 2;
     for (int idx = tid; idx < M * M; idx += NT) {
       const int i = idx / M, j = idx - i * M;
       double a = 0.0;
       if (j <= i) {
-        if (s0_load) a = A.s0[so + idx];
+        if (s0_load) a = (LAT && idx < 3 * NT) ? (idx < NT ? s0v[0] : (idx < 2 * NT ? s0v[1] : s0v[2])) : A.s0[so + idx];
         else {
           double ch[4];   // the children's records: four loads in flight, fixed summation order
           for (int c0 = 0; c0 < s_nch; c0 += 4) {
@@ -1229,7 +1322,8 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
       double ch[4];
       for (int c0 = 0; c0 < s_nch; c0 += 4) {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) ch[cc] = (c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0;
+        for (int cc = 0; cc < 4; ++cc)
+          ch[cc] = (LAT && c0 == 0) ? smv[cc] : ((c0 + cc < s_nch) ? A.acc[s_coff[min(c0 + cc, s_nch - 1)] + B0.acc_len + M * M + i] : 0.0);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) a += ch[cc];
       }
@@ -1287,16 +1381,23 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
   __syncthreads();
   // ---- pass 2: vector part of the records, -N_a' av_a + the children's
   double *rec = A.acc + B0.acc_off;
-  for (int k = tid; k < P; k += NT) {
+  const int kfirst = LAT ? (tid >= 64 ? k2 : NT - 64 + tid) : tid;   // LAT: waves 1-3 hold columns 0 .. 191 in registers; beyond: late
+  for (int k = kfirst; k < P; k += NT) {
     int t = 0;
     while (t + 1 < J && k >= s_ao[t + 1]) ++t;
     const int ma = s_am[t], i = k - s_ao[t];
     const double *avt = seg + t * 32;
+    const bool held = LAT && tid >= 64 && k == k2 && M <= 28;
     double ch[4];   // the children's vectors: requested first, added after the dot product in a fixed order
     const int nch = A.no_fwd ? 0 : s_nch;
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) ch[cc] = (cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0;
+    for (int cc = 0; cc < 4; ++cc) ch[cc] = held ? ch2[cc] : ((cc < nch) ? A.acc[s_coff[min(cc, max(nch - 1, 0))] + s_aoff[t] + ma * ma + i] : 0.0);
     double a = 0.0;
+    if (held) {
+#pragma unroll
+      for (int rr = 0; rr < 28; ++rr) a -= x2[rr] * avt[min(rr, 31)];
+      // (rows beyond M: x2 = 0 and avt = 0 -- the same no-ops the batches of eight below append)
+    } else
     for (int r0 = 0; r0 < M; r0 += 8) {
       double x[8];
 #pragma unroll
@@ -1316,6 +1417,8 @@ __global__ __launch_bounds__(NT, 5) void k_sample_lean(SampleFastArgs A) {
   }
   if (tid == 0 && s_fail) atomicMin(A.errflag, B0.level * 16 + (refgrp ? 10 : 11));
 }
+template __global__ void k_sample_lean<false>(SampleFastArgs);
+template __global__ void k_sample_lean<true>(SampleFastArgs);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Phase B, reference blocks of at most 27 rows, ONE BLOCK PER WAVE (four independent blocks per workgroup, no workgroup
@@ -1918,7 +2021,7 @@ __global__ void k_sample_leaf_wide(SampleArgs A);
 __global__ void k_sample_mfma(SampleFastArgs A);
 __global__ void k_gram(SampleFastArgs A);
 __global__ void k_gram_direct(SampleFastArgs A);
-__global__ void k_sample_lean(SampleFastArgs A);
+template <bool LAT> __global__ void k_sample_lean(SampleFastArgs A);
 __global__ void k_sample_wave(SampleFastArgs A);
 __global__ void k_sample_leaf(SampleFastArgs A);
 template <int NCH> __global__ void k_sample_leaf_seg(SampleFastArgs A);

@@ -1981,7 +1981,14 @@ static int sample_launch(st_handle h, int g_hi, int g_lo) {   // levels g_hi-1 .
           const size_t per = (((size_t)h->gd_stride + L.maxP + 32 + L.av_dbl + 64 + (size_t)std::max(L.maxM, 1) * CH_LD + 1) & ~(size_t)1);
           F.ldN = (int)per; F.Mrows = L.maxM;
           hipLaunchKernelGGL(k_sample_wave, dim3((L.gown_n + NT / 64 - 1) / (NT / 64)), dim3(NT), per * 8 * (NT / 64), h->stream, F);
-        } else { F.av_dbl = L.av_dbl + 224; hipLaunchKernelGGL(k_sample_lean, dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F); }
+        } else {
+          // levels that do not fill the chip (fewer groups than 2 x CUs x the five workgroups the occupancy variant fits): the
+          // latency variant -- every descriptor-only load of a block in one round trip (SPAMTREE_SAMPLE_LAT=0: never; identical draws)
+          static const bool lat_on = !(getenv("SPAMTREE_SAMPLE_LAT") && getenv("SPAMTREE_SAMPLE_LAT")[0] == '0');
+          F.av_dbl = L.av_dbl + 224;
+          if (lat_on && L.gown_n <= 2 * h->sm_count) hipLaunchKernelGGL((k_sample_lean<true>), dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F);
+          else hipLaunchKernelGGL((k_sample_lean<false>), dim3(L.gown_n), dim3(NT), L.lds_slean, h->stream, F);
+        }
       } else {
         if (A.do_gram && L.big_sample && h->gram_big) {
           // the theta-only parts first, on the matrix cores (k_gram_big); the sweep kernel then takes its cached branch
